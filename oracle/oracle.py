@@ -1,0 +1,198 @@
+"""ctypes binding of the CPU oracle (oracle/libsrt_oracle.so) -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the
+product package stanford_raytracer_amd never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "libsrt_oracle.so")
+SRCS = ["srt_oracle.c", "srt_oracle_scattered.c"]
+ROW = 20
+
+
+def build(force=False):
+    srcs = [os.path.join(HERE, s) for s in SRCS]
+    deps = srcs + [os.path.join(HERE, h) for h in ("srt_oracle.h", "srt_oracle_internal.h", "tricubic_matrix.h")]
+    if not force and os.path.exists(LIB) and all(os.path.getmtime(d) <= os.path.getmtime(LIB) for d in deps):
+        return LIB
+    cmd = ["gcc", "-O2", "-ffp-contract=off", "-fno-fast-math", "-shared", "-fPIC", "-o", LIB, *srcs, "-lm", "-lpthread"]
+    subprocess.check_call(cmd)
+    return LIB
+
+
+class Params(C.Structure):
+    _fields_ = [("dt0", C.c_double), ("dtmax", C.c_double), ("tmax", C.c_double), ("maxerr", C.c_double),
+                ("minalt", C.c_double), ("del_", C.c_double), ("maxsteps", C.c_int), ("root", C.c_int),
+                ("fixedstep", C.c_int), ("first_attempt_policy", C.c_int)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(LIB)
+        dp = C.POINTER(C.c_double)
+        ip = C.POINTER(C.c_int)
+        L.so_model_create_ngo.restype = C.c_void_p
+        L.so_model_create_ngo.argtypes = [C.c_char_p, C.c_int, C.c_int]
+        L.so_model_create_interp_file.restype = C.c_void_p
+        L.so_model_create_interp_file.argtypes = [C.c_char_p, C.c_int, C.c_int]
+        L.so_model_create_interp.restype = C.c_void_p
+        L.so_model_create_interp.argtypes = [C.c_int] * 4 + [dp, dp, dp, dp, C.c_int, C.c_int]
+        L.so_model_create_scattered_file.restype = C.c_void_p
+        L.so_model_create_scattered_file.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int,
+                                                     C.c_double, C.c_uint]
+        L.so_model_destroy.argtypes = [C.c_void_p]
+        L.so_model_nspec.argtypes = [C.c_void_p]
+        L.so_plasma_params.argtypes = [C.c_void_p, dp, dp, dp, dp, dp, dp]
+        L.so_dispersion_relation.restype = C.c_double
+        L.so_dispersion_relation.argtypes = [dp, C.c_double, C.c_int, dp, dp, dp, dp]
+        L.so_stix_parameters.argtypes = [C.c_double, C.c_int, dp, dp, dp, C.c_double, dp, dp, dp, dp, dp]
+        L.so_is_right_handed.argtypes = [C.c_double] * 5
+        L.so_solve_dispersion_relation.argtypes = [C.c_void_p, dp, C.c_double, dp, dp, dp]
+        L.so_dfdk.argtypes = [C.c_void_p, dp, C.c_double, dp, C.c_double, dp]
+        L.so_dfdw.restype = C.c_double
+        L.so_dfdw.argtypes = [C.c_void_p, dp, C.c_double, dp, C.c_double]
+        L.so_dfdx.argtypes = [C.c_void_p, dp, C.c_double, dp, C.c_double, dp]
+        L.so_evalrhs.argtypes = [C.c_void_p, dp, C.c_double, dp]
+        L.so_rk4.argtypes = [C.c_void_p, dp, C.c_double, C.c_double, dp]
+        L.so_rk45.argtypes = [C.c_void_p, dp, C.c_double, C.c_double, dp, dp]
+        L.so_raytracer_run.argtypes = [C.c_void_p, C.POINTER(Params), dp, dp, C.c_double, dp, C.c_int, ip, ip]
+        L.so_trace_batch.restype = C.c_long
+        L.so_trace_batch.argtypes = [C.c_void_p, C.POINTER(Params), C.c_long, dp, dp, dp, dp, C.c_int, ip, ip,
+                                     C.c_int]
+        L.so_dipole_tilt.argtypes = [C.c_int, C.c_int, dp]
+        L.so_speed_of_light.restype = C.c_double
+        _lib = L
+    return _lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+def _arr(v, n=None):
+    a = np.ascontiguousarray(np.asarray(v, dtype=np.float64))
+    if n is not None:
+        assert a.size == n
+    return a
+
+
+class Model:
+    def __init__(self, handle):
+        if not handle:
+            raise RuntimeError("oracle model creation failed")
+        self.h = C.c_void_p(handle)
+        self.nspec = lib().so_model_nspec(self.h)
+
+    @classmethod
+    def ngo(cls, configfile, yearday=2010001, msec=0):
+        return cls(lib().so_model_create_ngo(os.fsencode(configfile), yearday, msec))
+
+    @classmethod
+    def interp_file(cls, gridfile, yearday=2010001, msec=0):
+        return cls(lib().so_model_create_interp_file(os.fsencode(gridfile), yearday, msec))
+
+    @classmethod
+    def interp(cls, F, bounds, qs, ms, yearday=2010001, msec=0):
+        """F: array [nz, ny, nx, nspec] (C order) == file order species fastest, then x, y, z."""
+        F = _arr(F)
+        nz, ny, nx, nspec = F.shape
+        b, q, m = _arr(bounds, 6), _arr(qs, nspec), _arr(ms, nspec)
+        return cls(lib().so_model_create_interp(nspec, nx, ny, nz, _dp(b), _dp(q), _dp(m), _dp(F), yearday, msec))
+
+    @classmethod
+    def scattered_file(cls, ptsfile, yearday=2010001, msec=0, window_scale=1.5, order=2, exact=0,
+                       local_window_scale=5.0, perm_seed=1):
+        return cls(lib().so_model_create_scattered_file(os.fsencode(ptsfile), yearday, msec, window_scale, order,
+                                                        exact, local_window_scale, perm_seed))
+
+    def __del__(self):
+        try:
+            lib().so_model_destroy(self.h)
+        except Exception:
+            pass
+
+    # ---- layers
+    def plasma_params(self, x):
+        x = _arr(x, 3)
+        qs, Ns, ms, nus, B0 = (np.zeros(4), np.zeros(4), np.zeros(4), np.zeros(4), np.zeros(3))
+        lib().so_plasma_params(self.h, _dp(x), _dp(qs), _dp(Ns), _dp(ms), _dp(nus), _dp(B0))
+        return qs, Ns, ms, nus, B0
+
+    def disp(self, x, k, w):
+        """Returns [F, S, D, P, R, L, re k1, im k1, re k2, im k2] like ref_harness --mode=disp."""
+        x, k = _arr(x, 3), _arr(k, 3)
+        qs, Ns, ms, nus, B0 = self.plasma_params(x)
+        c = lib().so_speed_of_light()
+        n = _arr(k * c / w)
+        F = lib().so_dispersion_relation(_dp(n), w, self.nspec, _dp(qs), _dp(Ns), _dp(ms), _dp(B0))
+        o = [C.c_double() for _ in range(5)]
+        # sqrt(dot_product(B0,B0)) with the Fortran's association
+        b0mag = float(np.sqrt((B0[0] * B0[0] + B0[1] * B0[1]) + B0[2] * B0[2]))
+        lib().so_stix_parameters(w, self.nspec, _dp(qs), _dp(Ns), _dp(ms), b0mag, *[C.byref(v) for v in o])
+        k1, k2 = np.zeros(2), np.zeros(2)
+        lib().so_solve_dispersion_relation(self.h, _dp(k), w, _dp(x), _dp(k1), _dp(k2))
+        return np.array([F] + [v.value for v in o] + [k1[0], k1[1], k2[0], k2[1]])
+
+    def grad(self, x, k, w, del_):
+        """[dFdk(3), dFdw, dFdx(3), rhs(7)] like ref_harness --mode=grad."""
+        x, k = _arr(x, 3), _arr(k, 3)
+        dk, dx, rhs = np.zeros(3), np.zeros(3), np.zeros(7)
+        lib().so_dfdk(self.h, _dp(k), w, _dp(x), 1.0e-8, _dp(dk))
+        dw = lib().so_dfdw(self.h, _dp(k), w, _dp(x), 1.0e-8)
+        lib().so_dfdx(self.h, _dp(k), w, _dp(x), del_, _dp(dx))
+        args = _arr(np.concatenate([x, k, [w]]))
+        lib().so_evalrhs(self.h, _dp(args), del_, _dp(rhs))
+        return np.concatenate([dk, [dw], dx, rhs])
+
+    def step(self, args, dt, del_):
+        """[rk4(7), rk45 4th(7), rk45 5th(7)] like ref_harness --mode=step."""
+        args = _arr(args, 7)
+        r4, o4, o5 = np.zeros(7), np.zeros(7), np.zeros(7)
+        lib().so_rk4(self.h, _dp(args), del_, dt, _dp(r4))
+        lib().so_rk45(self.h, _dp(args), del_, dt, _dp(o4), _dp(o5))
+        return np.concatenate([r4, o4, o5])
+
+    def trace(self, pos0, dir0, w0, capacity=None, nthreads=1, **kw):
+        """Batch raytracer_run.  Returns (rows[nrays, capacity, 20], nrows[nrays], stopcond[nrays], steps)."""
+        p = make_params(**kw)
+        pos0 = _arr(pos0).reshape(-1, 3)
+        dir0 = _arr(dir0).reshape(-1, 3)
+        w0 = _arr(w0).reshape(-1)
+        n = pos0.shape[0]
+        if capacity is None:
+            capacity = p.maxsteps
+        rows = np.zeros((n, capacity, ROW)) if capacity > 0 else np.zeros((0,))
+        nrows = np.zeros(n, dtype=np.int32)
+        stop = np.zeros(n, dtype=np.int32)
+        steps = lib().so_trace_batch(self.h, C.byref(p), n, _dp(pos0), _dp(dir0), _dp(w0),
+                                     _dp(rows) if capacity > 0 else None, capacity, _ip(nrows), _ip(stop), nthreads)
+        return rows, nrows, stop, steps
+
+
+def make_params(dt0=1e-3, dtmax=0.1, tmax=1.0, maxerr=5e-4, minalt=6.4712e6, del_=1e-6, maxsteps=2000, root=2,
+                fixedstep=0, first_attempt_policy=0):
+    return Params(dt0, dtmax, tmax, maxerr, minalt, del_, maxsteps, root, fixedstep, first_attempt_policy)
+
+
+def is_right_handed(n2, phi, S, D, P):
+    return bool(lib().so_is_right_handed(n2, phi, S, D, P))
+
+
+def dipole_tilt(yearday, msec):
+    v = C.c_double()
+    lib().so_dipole_tilt(yearday, msec, C.byref(v))
+    return v.value
