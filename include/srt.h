@@ -1,0 +1,149 @@
+/* srt.h -- C ABI of the MI355X-native many-ray Haselgrove integrator (libsrt_hip.so).
+ *
+ * Drop-in boundary for ONE path of rareid2/Stanford_Raytracer: the ray loop of
+ * fortran/raytracer_driver.f95:1144-1232, i.e. the per-ray call
+ *     call raytracer_run(pos,time,vprel,vgrel,n,B0,qs,ms,Ns,nus,stopcond, pos0,dir0,w,dt0,dtmax,
+ *                        maxerr,maxsteps,minalt,root,tmax,fixedstep,del,funcPlasmaParams,data,
+ *                        raytracer_stopconditions)            (signature fortran/raytracer.f95:609-642)
+ * becomes one batched call, srt_trace_batch().  The reference's plugin callback
+ *     subroutine funcPlasmaParams(x, qs, Ns, ms, nus, B0, funcPlasmaParamsData)   (raytracer.f95:121-129)
+ * cannot be a host callback on a GPU path; its three in-scope implementations are selected by the
+ * model handle instead (modelnum 1 / 3 / 4 of raytracer_driver.f95:256-770) and are exposed for
+ * point queries through srt_plasma_params().
+ *
+ * Conventions: plain pointers and sizes, no C++ or torch types.  All arrays are HOST memory unless a
+ * function name ends in _device.  Vectors are AoS: pos0[i*3+c].  Every function returns 0 on success
+ * or a negative SRT_E* code; srt_last_error() gives the text.  Per-ray failures never abort a batch:
+ * they are reported through stopcond (same codes as raytracer.f95:324-353, plus SRT_STOP_NUMERIC for
+ * the reference's process-killing `stop` on an SVD failure, blas.f95:208-211).
+ * The library needs a gfx950 GPU; there is no CPU fallback.
+ */
+#ifndef SRT_H
+#define SRT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SRT_VERSION 1
+#define SRT_MAXSPEC 4
+/* one trajectory row: t, pos[3], vprel[3], vgrel[3], n[3], B0[3], Ns[4]  (the per-step outputs of
+ * raytracer_run; qs/ms/nus are per-model constants, see srt_model_species) */
+#define SRT_ROW 20
+
+enum {
+  SRT_OK = 0,
+  SRT_EINVAL = -1,  /* bad argument */
+  SRT_EIO = -2,     /* file could not be read / written / parsed */
+  SRT_EDEVICE = -3, /* HIP error or no gfx950 device */
+  SRT_ENOMEM = -4
+};
+
+/* stop codes, raytracer.f95:324-353 and :749-754 */
+enum {
+  SRT_STOP_TMAX = 0,    /* t >= tmax (also: fixed-step ray left the resonance cone, :900-905) */
+  SRT_STOP_MINALT = 1,  /* |pos| < minalt */
+  SRT_STOP_KZERO = 2,   /* |k| == 0 */
+  SRT_STOP_VGROUP = 3,  /* |vgrel| > 1.01 */
+  SRT_STOP_DT = 5,      /* dt < 1e-14 */
+  SRT_STOP_MAXSTEPS = 6,
+  SRT_STOP_NUMERIC = 9  /* ours: non-finite state where the reference would `stop` the process */
+};
+
+/* integrator parameters = the scalar arguments of raytracer_run + the driver's outputper */
+typedef struct srt_params {
+  double dt0, dtmax, tmax, maxerr, minalt;
+  double del;        /* FD step for dF/dx: 1e-4 for model 1, 1e-6 for models 3,4 (driver:251-252) */
+  int32_t maxsteps;
+  int32_t root;      /* 1 or 2 (2 = whistler) */
+  int32_t fixedstep; /* 1 = RK4, 0 = adaptive RKF45 */
+  int32_t outputper; /* keep rows 0, outputper, 2*outputper, ... (driver:1197) */
+  int32_t first_attempt_policy; /* 0: NaN error term => accept, no growth (flang; SURVEY A-1)
+                                   1: error from the k term alone (gfortran<=8) */
+  int32_t refill_threshold;     /* free lanes per wave before new rays are claimed (0 = default) */
+} srt_params;
+
+typedef struct srt_model srt_model; /* opaque; owns device copies of all model data */
+
+/* ---- library ---- */
+int srt_init(int device);             /* selects the HIP device; idempotent */
+const char *srt_last_error(void);
+int srt_device_info(char *name, int name_len, int *cu_count, int64_t *hbm_bytes);
+
+/* ---- models (replace ngosetup / interpsetup / scatteredinterpsetup + the TRANSFER'd state blob) ---- */
+/* modelnum=1: Ngo diffusive-equilibrium model; configfile is the legacy newray.in card file
+ * (ngo_dens_model.f95:29-160).  yearday/msec = itime of the adapters (dipole tilt). */
+int srt_model_create_ngo(const char *configfile, int yearday, int msec, srt_model **out);
+/* modelnum=3: regular grid of ln(N_s), text file in the format of
+ * gcpm_dens_model_buildgrid.f95:302-327 as read by interp_dens_model_adapter.f95:58-117 */
+int srt_model_create_interp_file(const char *gridfile, int yearday, int msec, srt_model **out);
+/* same, from host arrays: F[nz][ny][nx][nspec] (file order: species fastest, then x, y, z);
+ * derivs = NULL (finite differences as libtricubic.f95:722-793) or 7 arrays of F's shape in the
+ * order dfdx, dfdy, dfdz, d2fdxdy, d2fdxdz, d2fdydz, d3fdxdydz */
+int srt_model_create_interp(int nspec, int nx, int ny, int nz, const double bounds[6],
+                            const double *qs, const double *ms, const double *F,
+                            const double *const *derivs, int yearday, int msec, srt_model **out);
+/* modelnum=4: scattered ln(N_s) samples, text file of gcpm_dens_model_buildgrid_random.f95:210-225;
+ * parameters are the --scattered_interp_* flags of raytracer_driver.f95:690-728 */
+int srt_model_create_scattered_file(const char *ptsfile, int yearday, int msec, double window_scale,
+                                    int order, int exact, double local_window_scale, srt_model **out);
+void srt_model_destroy(srt_model *m);
+int srt_model_kind(const srt_model *m);  /* 1, 3 or 4 */
+int srt_model_nspec(const srt_model *m);
+int srt_model_species(const srt_model *m, double qs[SRT_MAXSPEC], double ms[SRT_MAXSPEC]);
+int64_t srt_model_device_bytes(const srt_model *m);
+
+/* ---- layered entry points (each mirrors one reference procedure, batched over n items) ---- */
+/* funcPlasmaParams: x[n][3] -> qs,Ns,ms,nus [n][4], B0[n][3] */
+int srt_plasma_params(srt_model *m, int64_t n, const double *x, double *qs, double *Ns, double *ms,
+                      double *nus, double *B0);
+/* dispersion_relation + stix_parameters + solve_dispersion_relation at (x,k,w):
+ * out[n][10] = F, S, D, P, R, L, Re k1, Im k1, Re k2, Im k2   (raytracer.f95:41-102, 408-502) */
+int srt_dispersion(srt_model *m, int64_t n, const double *x, const double *k, const double *w,
+                   double *out);
+/* dFdk(del=1e-8), dFdw(1e-8), dFdx(del), raytracer_evalrhs: out[n][14]  (raytracer.f95:118-314) */
+int srt_gradients(srt_model *m, int64_t n, const double *x, const double *k, const double *w,
+                  double del, double *out);
+/* one rk4 and one rk45 step from args[n][7] with dt[n]: out[n][21] = rk4(7), out4(7), out5(7)
+ * (raytracer.f95:504-596) */
+int srt_rk_step(srt_model *m, int64_t n, const double *args, const double *dt, double del,
+                double *out);
+
+/* ---- the hot path: replaces the driver's whole ray loop ---- */
+/* slots per ray = ceil(maxsteps/outputper) */
+int32_t srt_rows_per_ray(const srt_params *p);
+/* Inputs pos0/dir0 [nrays][3], w0[nrays].  Outputs (caller-allocated host arrays):
+ *   rows     [nrays][slots][SRT_ROW]   kept rows (row index r*outputper is stored in slot r)
+ *   nrows    [nrays]                   total rows T the ray produced (= accepted steps + 1)
+ *   stopcond [nrays]
+ * accepted_steps (optional) receives sum(nrows-1). */
+int srt_trace_batch(srt_model *m, const srt_params *p, int64_t nrays, const double *pos0,
+                    const double *dir0, const double *w0, double *rows, int32_t *nrows,
+                    int32_t *stopcond, int64_t *accepted_steps);
+/* Same with every buffer already resident in device memory (what bench.py times).
+ * d_pos0/d_dir0 are SoA on the device: [3][nrays].  stream = hipStream_t (NULL = default).
+ * d_counters: 4 x int64 scratch/outputs: [0] queue head (zeroed by the call), [1] accepted steps,
+ * [2] attempts, [3] reserved.  Asynchronous: returns after enqueue. */
+int srt_trace_batch_device(srt_model *m, const srt_params *p, int64_t nrays, const double *d_pos0,
+                           const double *d_dir0, const double *d_w0, double *d_rows,
+                           int32_t *d_nrows, int32_t *d_stopcond, int64_t *d_counters, void *stream);
+/* duration in ms of the most recent trace kernel on this model, measured with HIP events on the
+ * stream it ran on (synchronises that stream) */
+int srt_last_kernel_ms(srt_model *m, float *ms);
+
+/* ---- file formats of the boundary ---- */
+/* ray input file: 7 list-directed reals per line (raytracer_driver.f95:1146); returns count, fills
+ * malloc'd arrays the caller frees with srt_free */
+int64_t srt_read_rays_file(const char *path, double **pos0, double **dir0, double **w0);
+/* .ray writer, record format of raytracer_driver.f95:1197-1217; raynum0 = number of first ray (1) */
+int srt_write_ray_file(const char *path, int append, int64_t raynum0, int64_t nrays,
+                       const srt_params *p, const srt_model *m, const double *w0, const double *rows,
+                       const int32_t *nrows, const int32_t *stopcond);
+void srt_free(void *p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,254 @@
+"""Host-side mirror of the reference's interface for the hot path, over the C ABI (include/srt.h).
+
+Names follow the reference: a *model* is what `--modelnum` selects and `setup()` builds
+(raytracer_driver.f95:256-770); `plasma_params` is `funcPlasmaParams` (raytracer.f95:121-129);
+`trace` is the driver's ray loop around `raytracer_run` (raytracer_driver.f95:1144-1232).
+The library is HIP-only: importing works anywhere, but every call needs an MI355X and raises
+`SrtError` otherwise -- there is no CPU fallback.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+ROW = 20
+STOP_NAMES = {0: "tmax", 1: "minalt", 2: "k=0", 3: "vgroup", 5: "dt", 6: "maxsteps", 9: "numeric"}
+
+
+class SrtError(RuntimeError):
+    pass
+
+
+class Params(C.Structure):
+    """srt_params: scalar arguments of raytracer_run + the driver's outputper."""
+    _fields_ = [("dt0", C.c_double), ("dtmax", C.c_double), ("tmax", C.c_double), ("maxerr", C.c_double),
+                ("minalt", C.c_double), ("del_", C.c_double), ("maxsteps", C.c_int32), ("root", C.c_int32),
+                ("fixedstep", C.c_int32), ("outputper", C.c_int32), ("first_attempt_policy", C.c_int32),
+                ("refill_threshold", C.c_int32)]
+
+
+def make_params(dt0=1e-3, dtmax=0.1, tmax=1.0, maxerr=5e-4, minalt=6371.2e3 + 100e3, del_=1e-6, maxsteps=2000,
+                root=2, fixedstep=0, outputper=1, first_attempt_policy=0, refill_threshold=0):
+    return Params(dt0, dtmax, tmax, maxerr, minalt, del_, maxsteps, root, fixedstep, outputper,
+                  first_attempt_policy, refill_threshold)
+
+
+_lib = None
+dp = C.POINTER(C.c_double)
+ip = C.POINTER(C.c_int32)
+
+
+def library_path():
+    return _build.LIB
+
+
+def lib():
+    """Load libsrt_hip.so (building it if the sources are newer).  Fails loudly when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB
+    if not os.path.exists(path):
+        _build.build()
+    if not os.path.exists(path):
+        raise SrtError("libsrt_hip.so is missing and could not be built; the HIP path is the only path")
+    L = C.CDLL(path)
+    vp = C.c_void_p
+    L.srt_last_error.restype = C.c_char_p
+    L.srt_init.argtypes = [C.c_int]
+    L.srt_device_info.argtypes = [C.c_char_p, C.c_int, ip, C.POINTER(C.c_int64)]
+    L.srt_model_create_ngo.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(vp)]
+    L.srt_model_create_interp_file.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(vp)]
+    L.srt_model_create_interp.argtypes = [C.c_int] * 4 + [dp, dp, dp, dp, C.POINTER(dp), C.c_int, C.c_int,
+                                                          C.POINTER(vp)]
+    L.srt_model_create_scattered_file.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int,
+                                                  C.c_double, C.POINTER(vp)]
+    L.srt_model_destroy.argtypes = [vp]
+    L.srt_model_destroy.restype = None
+    L.srt_model_kind.argtypes = [vp]
+    L.srt_model_nspec.argtypes = [vp]
+    L.srt_model_species.argtypes = [vp, dp, dp]
+    L.srt_model_device_bytes.argtypes = [vp]
+    L.srt_model_device_bytes.restype = C.c_int64
+    L.srt_plasma_params.argtypes = [vp, C.c_int64, dp, dp, dp, dp, dp, dp]
+    L.srt_dispersion.argtypes = [vp, C.c_int64, dp, dp, dp, dp]
+    L.srt_gradients.argtypes = [vp, C.c_int64, dp, dp, dp, C.c_double, dp]
+    L.srt_rk_step.argtypes = [vp, C.c_int64, dp, dp, C.c_double, dp]
+    L.srt_rows_per_ray.argtypes = [C.POINTER(Params)]
+    L.srt_rows_per_ray.restype = C.c_int32
+    L.srt_trace_batch.argtypes = [vp, C.POINTER(Params), C.c_int64, dp, dp, dp, dp, ip, ip, C.POINTER(C.c_int64)]
+    L.srt_trace_batch_device.argtypes = [vp, C.POINTER(Params), C.c_int64, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.srt_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.srt_read_rays_file.argtypes = [C.c_char_p, C.POINTER(dp), C.POINTER(dp), C.POINTER(dp)]
+    L.srt_read_rays_file.restype = C.c_int64
+    L.srt_write_ray_file.argtypes = [C.c_char_p, C.c_int, C.c_int64, C.c_int64, C.POINTER(Params), vp, dp, dp, ip, ip]
+    L.srt_free.argtypes = [vp]
+    L.srt_free.restype = None
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise SrtError("srt error %d: %s" % (rc, (lib().srt_last_error() or b"").decode()))
+
+
+def _f64(a, shape=None):
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+def _dp(a):
+    return a.ctypes.data_as(dp)
+
+
+def init(device=0):
+    _check(lib().srt_init(device))
+
+
+def device_info():
+    name = C.create_string_buffer(256)
+    cu = C.c_int32()
+    mem = C.c_int64()
+    _check(lib().srt_device_info(name, 256, C.byref(cu), C.byref(mem)))
+    return {"name": name.value.decode(), "cu_count": cu.value, "hbm_bytes": mem.value}
+
+
+class Model:
+    """Opaque density/field model living on the device (replaces the adapters' state blob)."""
+
+    def __init__(self, handle):
+        self.h = handle
+        self.kind = lib().srt_model_kind(handle)
+        self.nspec = lib().srt_model_nspec(handle)
+
+    @classmethod
+    def ngo(cls, configfile, yearday=2010001, msec=0):
+        h = C.c_void_p()
+        _check(lib().srt_model_create_ngo(os.fsencode(configfile), yearday, msec, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def interp_file(cls, gridfile, yearday=2010001, msec=0):
+        h = C.c_void_p()
+        _check(lib().srt_model_create_interp_file(os.fsencode(gridfile), yearday, msec, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def interp(cls, F, bounds, qs, ms, derivs=None, yearday=2010001, msec=0):
+        """F[nz, ny, nx, nspec] = ln N_s in the grid file's order (species fastest, then x, y, z)."""
+        F = _f64(F)
+        nz, ny, nx, ns = F.shape
+        b, q, m = _f64(bounds, 6), _f64(qs, ns), _f64(ms, ns)
+        dptr = None
+        keep = []
+        if derivs is not None:
+            keep = [_f64(d, F.shape) for d in derivs]
+            dptr = (dp * 7)(*[_dp(d) for d in keep])
+        h = C.c_void_p()
+        _check(lib().srt_model_create_interp(ns, nx, ny, nz, _dp(b), _dp(q), _dp(m), _dp(F), dptr, yearday, msec,
+                                             C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def scattered_file(cls, ptsfile, yearday=2010001, msec=0, window_scale=1.5, order=2, exact=0,
+                       local_window_scale=5.0):
+        h = C.c_void_p()
+        _check(lib().srt_model_create_scattered_file(os.fsencode(ptsfile), yearday, msec, window_scale, order,
+                                                     exact, local_window_scale, C.byref(h)))
+        return cls(h)
+
+    def close(self):
+        if self.h:
+            lib().srt_model_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def device_bytes(self):
+        return lib().srt_model_device_bytes(self.h)
+
+    def species(self):
+        qs, ms = np.zeros(4), np.zeros(4)
+        _check(lib().srt_model_species(self.h, _dp(qs), _dp(ms)))
+        return qs, ms
+
+    # ---- layered entry points
+    def plasma_params(self, x):
+        """funcPlasmaParams at x[n,3] -> [n,19] = qs(4) Ns(4) ms(4) nus(4) B0(3)."""
+        x = _f64(x, (-1, 3))
+        n = x.shape[0]
+        qs, Ns, ms, nus, B0 = (np.zeros((n, 4)) for _ in range(4)) if False else \
+            (np.zeros((n, 4)), np.zeros((n, 4)), np.zeros((n, 4)), np.zeros((n, 4)), np.zeros((n, 3)))
+        _check(lib().srt_plasma_params(self.h, n, _dp(x), _dp(qs), _dp(Ns), _dp(ms), _dp(nus), _dp(B0)))
+        return np.concatenate([qs, Ns, ms, nus, B0], axis=1)
+
+    def dispersion(self, x, k, w):
+        x, k, w = _f64(x, (-1, 3)), _f64(k, (-1, 3)), _f64(w, (-1,))
+        out = np.zeros((x.shape[0], 10))
+        _check(lib().srt_dispersion(self.h, x.shape[0], _dp(x), _dp(k), _dp(w), _dp(out)))
+        return out
+
+    def gradients(self, x, k, w, del_):
+        x, k, w = _f64(x, (-1, 3)), _f64(k, (-1, 3)), _f64(w, (-1,))
+        out = np.zeros((x.shape[0], 14))
+        _check(lib().srt_gradients(self.h, x.shape[0], _dp(x), _dp(k), _dp(w), del_, _dp(out)))
+        return out
+
+    def rk_step(self, args, dt, del_):
+        args = _f64(args, (-1, 7))
+        dt = _f64(np.broadcast_to(dt, (args.shape[0],)))
+        out = np.zeros((args.shape[0], 21))
+        _check(lib().srt_rk_step(self.h, args.shape[0], _dp(args), _dp(dt), del_, _dp(out)))
+        return out
+
+    # ---- the hot path
+    def trace(self, pos0, dir0, w0, params=None, **kw):
+        """Batched raytracer_run.  Returns rows[n, slots, 20], nrows[n], stopcond[n], accepted_steps."""
+        p = params if params is not None else make_params(**kw)
+        pos0, dir0, w0 = _f64(pos0, (-1, 3)), _f64(dir0, (-1, 3)), _f64(w0, (-1,))
+        n = pos0.shape[0]
+        slots = lib().srt_rows_per_ray(C.byref(p))
+        rows = np.zeros((n, slots, ROW))
+        nrows = np.zeros(n, dtype=np.int32)
+        stop = np.zeros(n, dtype=np.int32)
+        steps = C.c_int64()
+        _check(lib().srt_trace_batch(self.h, C.byref(p), n, _dp(pos0), _dp(dir0), _dp(w0), _dp(rows),
+                                     nrows.ctypes.data_as(ip), stop.ctypes.data_as(ip), C.byref(steps)))
+        return rows, nrows, stop, steps.value
+
+    def last_kernel_ms(self):
+        ms = C.c_float()
+        _check(lib().srt_last_kernel_ms(self.h, C.byref(ms)))
+        return ms.value
+
+
+def read_rays_file(path):
+    a, b, c = dp(), dp(), dp()
+    n = lib().srt_read_rays_file(os.fsencode(path), C.byref(a), C.byref(b), C.byref(c))
+    if n < 0:
+        _check(int(n))
+    pos0 = np.ctypeslib.as_array(a, (n, 3)).copy() if n else np.zeros((0, 3))
+    dir0 = np.ctypeslib.as_array(b, (n, 3)).copy() if n else np.zeros((0, 3))
+    w0 = np.ctypeslib.as_array(c, (n,)).copy() if n else np.zeros((0,))
+    for ptr in (a, b, c):
+        lib().srt_free(ptr)
+    return pos0, dir0, w0
+
+
+def write_ray_file(path, model, params, w0, rows, nrows, stopcond, raynum0=1, append=False):
+    w0 = _f64(w0, (-1,))
+    rows = _f64(rows)
+    nrows = np.ascontiguousarray(nrows, dtype=np.int32)
+    stopcond = np.ascontiguousarray(stopcond, dtype=np.int32)
+    _check(lib().srt_write_ray_file(os.fsencode(path), int(append), raynum0, w0.shape[0], C.byref(params), model.h,
+                                    _dp(w0), _dp(rows), nrows.ctypes.data_as(ip), stopcond.ctypes.data_as(ip)))

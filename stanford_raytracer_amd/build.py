@@ -1,0 +1,61 @@
+"""Build the HIP library (libsrt_hip.so) and the raytracer-compatible CLI for gfx950, in-tree.
+
+hipcc cross-compiles without a GPU.  Outputs (git-ignored, shipped to the GPU box by gpurun):
+    stanford_raytracer_amd/lib/libsrt_hip.so
+    stanford_raytracer_amd/bin/raytracer
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, "csrc")
+LIBDIR = os.path.join(PKG, "lib")
+BINDIR = os.path.join(PKG, "bin")
+LIB = os.path.join(LIBDIR, "libsrt_hip.so")
+CLI = os.path.join(BINDIR, "raytracer")
+ARCH = "gfx950"
+
+LIB_SRCS = ["srt_api.hip", "srt_host.cpp"]
+CLI_SRCS = ["srt_cli.cpp"]
+HEADERS = ["srt_device.hpp", "srt_models.hpp", "srt_kernels.hpp", "srt_host.hpp", "tricubic_matrix.h",
+           os.path.join("..", "..", "include", "srt.h")]
+
+
+def _hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: the MI355X path cannot be built (there is no CPU fallback)")
+    return exe
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force=False, verbose=False):
+    os.makedirs(LIBDIR, exist_ok=True)
+    os.makedirs(BINDIR, exist_ok=True)
+    deps = [os.path.join(CSRC, f) for f in LIB_SRCS + HEADERS] + [os.path.abspath(__file__)]
+    if force or _stale(LIB, deps):
+        cmd = [_hipcc(), "-O3", "--offload-arch=" + ARCH, "-std=c++17", "-fPIC", "-shared", "-o", LIB] + \
+              [os.path.join(CSRC, f) for f in LIB_SRCS]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    cli_src = [os.path.join(CSRC, f) for f in CLI_SRCS]
+    if all(os.path.exists(s) for s in cli_src) and (force or _stale(CLI, cli_src + [LIB])):
+        cmd = [_hipcc(), "-O2", "-std=c++17", "-o", CLI] + cli_src + \
+              ["-L" + LIBDIR, "-lsrt_hip", "-Wl,-rpath,$ORIGIN/../lib"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True)

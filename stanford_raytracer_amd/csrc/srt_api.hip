@@ -1,0 +1,636 @@
+// srt_api.hip -- C ABI (include/srt.h) of the MI355X-native many-ray Haselgrove integrator.
+// Host side: model construction (device-resident tables), kernel launches, HIP-event timing.
+// There is no CPU fallback: every entry point fails with SRT_EDEVICE when no GPU is usable.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/srt.h"
+#include "srt_host.hpp"
+#include "srt_kernels.hpp"
+#include "tricubic_matrix.h"
+
+using namespace srt;
+
+// ------------------------------------------------------------------------------------------ errors
+static thread_local std::string g_err;
+int srt_set_error(int code, const char *fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+extern "C" const char *srt_last_error(void) { return g_err.c_str(); }
+
+#define HIP_OK(expr)                                                                          \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess)                                                                     \
+      return srt_set_error(e_ == hipErrorOutOfMemory ? SRT_ENOMEM : SRT_EDEVICE, "%s: %s", #expr, \
+                           hipGetErrorString(e_));                                            \
+  } while (0)
+
+static int g_device = -1;
+extern "C" int srt_init(int device) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+    return srt_set_error(SRT_EDEVICE, "no HIP device available (this library has no CPU path)");
+  if (device < 0 || device >= n) return srt_set_error(SRT_EINVAL, "device %d out of range (%d devices)", device, n);
+  HIP_OK(hipSetDevice(device));
+  g_device = device;
+  return SRT_OK;
+}
+static int ensure_init() {
+  if (g_device >= 0) return hipSetDevice(g_device) == hipSuccess ? SRT_OK : srt_set_error(SRT_EDEVICE, "hipSetDevice failed");
+  return srt_init(0);
+}
+extern "C" int srt_device_info(char *name, int name_len, int *cu_count, int64_t *hbm_bytes) {
+  int rc = ensure_init();
+  if (rc) return rc;
+  hipDeviceProp_t p;
+  HIP_OK(hipGetDeviceProperties(&p, g_device));
+  if (name && name_len > 0) snprintf(name, name_len, "%s (%s)", p.name, p.gcnArchName);
+  if (cu_count) *cu_count = p.multiProcessorCount;
+  if (hbm_bytes) *hbm_bytes = (int64_t)p.totalGlobalMem;
+  return SRT_OK;
+}
+
+// ------------------------------------------------------------------------------------------ model
+struct srt_model {
+  int kind = 0, nspec = 0;
+  Common cm{};
+  NgoModel ngo{};
+  InterpModel interp{};
+  double *d_coef = nullptr;
+  void *d_model = nullptr;   // device copy of ngo / interp (kernels read it through scalar loads)
+  Common *d_common = nullptr;
+  int64_t device_bytes = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool timed = false;
+  int cu_count = 256;
+};
+
+static void fill_common(Common &cm, int nspec, const double *qs, const double *ms, int yearday, int msec) {
+  memset(&cm, 0, sizeof cm);
+  cm.sp.nspec = nspec;
+  double maxq = 0.0, minm = 0.0;
+  for (int s = 0; s < nspec; ++s) {
+    cm.sp.q[s] = qs[s];
+    cm.sp.m[s] = ms[s];
+    cm.sp.c[s] = qs[s] * qs[s] / ms[s] / EPS0;
+    cm.sp.g[s] = qs[s] / ms[s];
+    if (fabs(qs[s]) > maxq) maxq = fabs(qs[s]);
+    if (s == 0 || ms[s] < minm) minm = ms[s];
+  }
+  cm.sp.maxq2 = maxq * maxq;
+  cm.sp.minm_eps0 = minm * EPS0;
+  const double MU0 = PI * 4e-7; // constants.f95:6
+  cm.C = sqrt(1.0 / EPS0 / MU0); // constants.f95:7
+  double mu = srt_host::dipole_tilt(yearday, msec);
+  cm.fld.cm = cos(mu);
+  cm.fld.sm = sin(mu);
+  cm.fld.bo_re3 = (.312 / 10000.0) * R_E * R_E * R_E;
+}
+
+static int model_finish(srt_model *m) {
+  HIP_OK(hipMalloc(&m->d_common, sizeof(Common)));
+  HIP_OK(hipMemcpy(m->d_common, &m->cm, sizeof(Common), hipMemcpyHostToDevice));
+  if (m->kind == 1) {
+    HIP_OK(hipMalloc(&m->d_model, sizeof(NgoModel)));
+    HIP_OK(hipMemcpy(m->d_model, &m->ngo, sizeof(NgoModel), hipMemcpyHostToDevice));
+  } else if (m->kind == 3) {
+    HIP_OK(hipMalloc(&m->d_model, sizeof(InterpModel)));
+    HIP_OK(hipMemcpy(m->d_model, &m->interp, sizeof(InterpModel), hipMemcpyHostToDevice));
+  }
+  hipDeviceProp_t p;
+  HIP_OK(hipGetDeviceProperties(&p, g_device));
+  m->cu_count = p.multiProcessorCount;
+  HIP_OK(hipEventCreate(&m->ev0));
+  HIP_OK(hipEventCreate(&m->ev1));
+  return SRT_OK;
+}
+
+extern "C" void srt_model_destroy(srt_model *m) {
+  if (!m) return;
+  if (m->d_coef) (void)hipFree(m->d_coef);
+  if (m->d_model) (void)hipFree(m->d_model);
+  if (m->d_common) (void)hipFree(m->d_common);
+  if (m->ev0) (void)hipEventDestroy(m->ev0);
+  if (m->ev1) (void)hipEventDestroy(m->ev1);
+  delete m;
+}
+extern "C" int srt_model_kind(const srt_model *m) { return m ? m->kind : 0; }
+extern "C" int srt_model_nspec(const srt_model *m) { return m ? m->nspec : 0; }
+extern "C" int64_t srt_model_device_bytes(const srt_model *m) { return m ? m->device_bytes : 0; }
+extern "C" int srt_model_species(const srt_model *m, double qs[SRT_MAXSPEC], double ms[SRT_MAXSPEC]) {
+  if (!m) return srt_set_error(SRT_EINVAL, "null model");
+  for (int s = 0; s < SRT_MAXSPEC; ++s) {
+    qs[s] = s < m->nspec ? m->cm.sp.q[s] : 0.0;
+    ms[s] = s < m->nspec ? m->cm.sp.m[s] : 0.0;
+  }
+  return SRT_OK;
+}
+
+// ---- Ngo: normalisation of ane0 (ngo_dens_model.f95:120-123) needs one evaluation of dens() -------
+__global__ void ngo_norm_kernel(NgoModel g, double z1, double sinz22, double latitu, double *out) {
+  double Ns[4];
+  g.dens_core(z1, sinz22, latitu, Ns);
+  out[0] = Ns[0] * 1.0e-6; // ani(1)
+}
+
+extern "C" int srt_model_create_ngo(const char *configfile, int yearday, int msec, srt_model **out) {
+  if (!configfile || !out) return srt_set_error(SRT_EINVAL, "null argument");
+  int rc = ensure_init();
+  if (rc) return rc;
+  srt_host::NgoConfig cfg;
+  std::string err;
+  if (!srt_host::read_newray(configfile, cfg, err)) return srt_set_error(SRT_EIO, "%s: %s", configfile, err.c_str());
+  srt_model *m = new srt_model;
+  m->kind = 1;
+  m->nspec = 4;
+  NgoModel &g = m->ngo;
+  memset(&g, 0, sizeof g);
+  g.r0 = 6370.0;
+  g.pi32 = (double)3.141592653589793f; // default-real literal, ngo_dens_model.f95:36 (SURVEY A-6)
+  g.num = cfg.num;
+  g.kducts = cfg.kducts;
+  g.kinit = 2;
+  g.therm = cfg.therm;
+  g.rbase = cfg.rbase;
+  g.ane0 = cfg.ane0;
+  for (int i = 0; i < 5; ++i) g.alpha0[i] = cfg.alpha0[i];
+  g.rzero = cfg.rzero;
+  g.scbot = cfg.scbot;
+  g.lk = cfg.lk;
+  g.expk = cfg.expk;
+  g.ddk = cfg.ddk;
+  g.rconsn = cfg.rconsn;
+  g.scr = cfg.scr;
+  for (int k = 0; k < 10; ++k) {
+    g.l0[k] = cfg.l0[k]; g.def[k] = cfg.def[k]; g.dd[k] = cfg.dd[k];
+    g.rducln[k] = cfg.rducln[k]; g.rducun[k] = cfg.rducun[k];
+    g.rducls[k] = cfg.rducls[k]; g.rducus[k] = cfg.rducus[k];
+    g.sidedu[k] = cfg.sidedu[k];
+    g.hl2n[k] = cfg.hducln[k] * cfg.hducln[k]; g.hl2s[k] = cfg.hducls[k] * cfg.hducls[k];
+    g.hu2n[k] = cfg.hducun[k] * cfg.hducun[k]; g.hu2s[k] = cfg.hducus[k] * cfg.hducus[k];
+  }
+  // ane0 <- ane0*dsdens/ani(1) at (dsrrng, dsrlat)  (:120-123); grarad is built on the float32 pi
+  double radgra = 180.0 / g.pi32, grarad = 1.0 / radgra;
+  double z2 = (90.0 - cfg.dsrlat) * grarad;
+  double z1 = cfg.dsrrng * g.r0;
+  double s2 = sin(z2);
+  double *d_out = nullptr;
+  double ani1 = 0.0;
+  if (hipMalloc(&d_out, sizeof(double)) != hipSuccess) {
+    delete m;
+    return srt_set_error(SRT_ENOMEM, "hipMalloc failed");
+  }
+  // the latitude dens() sees during this call is the last satellite latitude read (:64)
+  hipLaunchKernelGGL(ngo_norm_kernel, dim3(1), dim3(1), 0, 0, g, z1, s2 * s2, cfg.last_latitu, d_out);
+  hipError_t e = hipMemcpy(&ani1, d_out, sizeof(double), hipMemcpyDeviceToHost);
+  (void)hipFree(d_out);
+  if (e != hipSuccess) {
+    delete m;
+    return srt_set_error(SRT_EDEVICE, "ngo normalisation kernel failed: %s", hipGetErrorString(e));
+  }
+  g.ane0 = g.ane0 * cfg.dsdens / ani1;
+  const double e_ = 1.602e-19;
+  double qs[4] = {e_ * -1.0, e_, e_, e_};
+  double ms[4] = {9.10938188e-31, 1.6726e-27, 4.0 * 1.6726e-27, 16.0 * 1.6726e-27};
+  fill_common(m->cm, 4, qs, ms, yearday, msec);
+  rc = model_finish(m);
+  if (rc) {
+    srt_model_destroy(m);
+    return rc;
+  }
+  *out = m;
+  return SRT_OK;
+}
+
+// ---- interp: finite-difference derivatives + coefficient expansion on the device --------------------
+struct GridDims {
+  int nspec, nx, ny, nz;
+};
+__device__ __forceinline__ size_t gidx(const GridDims &g, int s, int i, int j, int k) {
+  return (((size_t)k * g.ny + j) * g.nx + i) * g.nspec + s;
+}
+// tricubic_compute_finite_difference_derivatives, one axis (libtricubic.f95:736-790)
+__global__ void fd_axis_kernel(GridDims g, const double *src, double *dst, int axis, double h) {
+  size_t total = (size_t)g.nspec * g.nx * g.ny * g.nz;
+  for (size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (size_t)gridDim.x * blockDim.x) {
+    int s = (int)(id % g.nspec);
+    size_t r = id / g.nspec;
+    int i = (int)(r % g.nx);
+    r /= g.nx;
+    int j = (int)(r % g.ny);
+    int k = (int)(r / g.ny);
+    int c[3] = {i, j, k};
+    int n[3] = {g.nx, g.ny, g.nz};
+    int lo[3] = {i, j, k}, hi[3] = {i, j, k};
+    int a = c[axis], na = n[axis];
+    double v;
+    if (a == 0) {
+      hi[axis] = 1;
+      v = (src[gidx(g, s, hi[0], hi[1], hi[2])] - src[gidx(g, s, lo[0], lo[1], lo[2])]) / h;
+    } else if (a == na - 1) {
+      lo[axis] = na - 2;
+      v = (src[gidx(g, s, hi[0], hi[1], hi[2])] - src[gidx(g, s, lo[0], lo[1], lo[2])]) / h;
+    } else {
+      lo[axis] = a - 1;
+      hi[axis] = a + 1;
+      v = (src[gidx(g, s, hi[0], hi[1], hi[2])] - src[gidx(g, s, lo[0], lo[1], lo[2])]) / 2.0 / h;
+    }
+    dst[id] = v;
+  }
+}
+
+struct ArrPtrs {
+  const double *a[8];
+};
+__constant__ short c_tri_ptr[65];
+__constant__ signed char c_tri_col[TRI_NNZ];
+__constant__ signed char c_tri_val[TRI_NNZ];
+
+// tricubic_get_coeff for every cell (libtricubic.f95:638-656,715-720) with the corner gathering,
+// clamping and sticky derivative-zeroing flags of tricubic_interpolate_at (:859-921; SURVEY A-7).
+// One 64-thread block per (cell, species): thread t first gathers constraint b[t] (t = 8*family +
+// corner), then computes coefficient row t of the sparse 64x64 product.
+__global__ __launch_bounds__(64) void build_coeffs_kernel(GridDims g, ArrPtrs arrs, double dx, double dy, double dz,
+                                                          double *coef, long long npairs) {
+  __shared__ double b[64];
+  const int t = threadIdx.x;
+  const int q = t >> 3, l = t & 7;
+  for (long long pair = blockIdx.x; pair < npairs; pair += gridDim.x) {
+    long long cell = pair / g.nspec;
+    int s = (int)(pair % g.nspec);
+    int ci = (int)(cell % (g.nx + 1));
+    long long r = cell / (g.nx + 1);
+    int cj = (int)(r % (g.ny + 1));
+    int ck = (int)(r / (g.ny + 1));
+    int it = ci + (l & 1), jt = cj + ((l >> 1) & 1), kt = ck + (l >> 2); // 1-based corner indices
+    it = it < 1 ? 1 : (it > g.nx ? g.nx : it);
+    jt = jt < 1 ? 1 : (jt > g.ny ? g.ny : jt);
+    kt = kt < 1 ? 1 : (kt > g.nz ? g.nz : kt);
+    // flags are set by the first clamped corner and never reset inside the corner loop
+    bool fi = (ci == 0) || (ci == g.nx && l >= 1);
+    bool fj = (cj == 0) || (cj == g.ny && l >= 2);
+    bool fk = (ck == 0) || (ck == g.nz && l >= 4);
+    double v = arrs.a[q][gidx(g, s, it - 1, jt - 1, kt - 1)];
+    bool zero = false;
+    switch (q) {
+    case 1: v = v * dx; zero = fi; break;
+    case 2: v = v * dy; zero = fj; break;
+    case 3: v = v * dz; zero = fk; break;
+    case 4: v = v * dx * dy; zero = fi || fj; break;
+    case 5: v = v * dx * dz; zero = fi || fk; break;
+    case 6: v = v * dy * dz; zero = fj || fk; break;
+    case 7: v = v * dx * dy * dz; zero = fi || fj || fk; break;
+    default: break;
+    }
+    __syncthreads();
+    b[t] = zero ? 0.0 : v;
+    __syncthreads();
+    double acc = 0.0;
+    for (int e = c_tri_ptr[t]; e < c_tri_ptr[t + 1]; ++e) acc += (double)c_tri_val[e] * b[(int)c_tri_col[e]];
+    coef[(size_t)pair * 64 + t] = acc;
+  }
+}
+
+extern "C" int srt_model_create_interp(int nspec, int nx, int ny, int nz, const double bounds[6],
+                                       const double *qs, const double *ms, const double *F,
+                                       const double *const *derivs, int yearday, int msec, srt_model **out) {
+  if (!bounds || !qs || !ms || !F || !out) return srt_set_error(SRT_EINVAL, "null argument");
+  if (nspec < 1 || nspec > SRT_MAXSPEC) return srt_set_error(SRT_EINVAL, "nspec=%d unsupported (1..%d)", nspec, SRT_MAXSPEC);
+  if (nx < 2 || ny < 2 || nz < 2) return srt_set_error(SRT_EINVAL, "grid must have >= 2 nodes per axis");
+  int rc = ensure_init();
+  if (rc) return rc;
+  const size_t nnode = (size_t)nx * ny * nz, n = nnode * nspec;
+  const size_t ncell = (size_t)(nx + 1) * (ny + 1) * (nz + 1);
+  if (ncell >= (size_t)1 << 31) return srt_set_error(SRT_EINVAL, "grid too large");
+  GridDims g{nspec, nx, ny, nz};
+  // interp_dens_model_adapter.f95:87-89
+  double dx = (bounds[1] - bounds[0]) / (nx - 1.0);
+  double dy = (bounds[3] - bounds[2]) / (ny - 1.0);
+  double dz = (bounds[5] - bounds[4]) / (nz - 1.0);
+  double *d_arr[8] = {nullptr};
+  double *d_coef = nullptr;
+  auto cleanup = [&]() {
+    for (int a = 0; a < 8; ++a)
+      if (d_arr[a]) (void)hipFree(d_arr[a]);
+  };
+  for (int a = 0; a < 8; ++a) {
+    if (hipMalloc(&d_arr[a], n * sizeof(double)) != hipSuccess) {
+      cleanup();
+      return srt_set_error(SRT_ENOMEM, "hipMalloc of grid arrays failed (%zu bytes each)", n * sizeof(double));
+    }
+  }
+  hipError_t e = hipMemcpy(d_arr[0], F, n * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    if (derivs) {
+      for (int a = 1; a < 8 && e == hipSuccess; ++a)
+        e = hipMemcpy(d_arr[a], derivs[a - 1], n * sizeof(double), hipMemcpyHostToDevice);
+    } else {
+      for (int a = 1; a < 8 && e == hipSuccess; ++a) e = hipMemset(d_arr[a], 0, n * sizeof(double));
+      int blocks = (int)((n + 255) / 256 < 65535 * 4 ? (n + 255) / 256 : 65535 * 4);
+      auto fd = [&](int src, int dst, int axis, double h) {
+        hipLaunchKernelGGL(fd_axis_kernel, dim3(blocks), dim3(256), 0, 0, g, (const double *)d_arr[src], d_arr[dst], axis, h);
+      };
+      // order and guards of libtricubic.f95:736-790
+      if (nx > 2) fd(0, 1, 0, dx);
+      if (ny > 2) fd(0, 2, 1, dy);
+      if (nz > 2) fd(0, 3, 2, dz);
+      if (nx > 2 && ny > 2) fd(2, 4, 0, dx);
+      if (nx > 2 && nz > 2) fd(3, 5, 0, dx);
+      if (ny > 2 && nz > 2) fd(3, 6, 1, dy);
+      if (nx > 2 && ny > 2 && nz > 2) fd(6, 7, 0, dx);
+    }
+  }
+  if (e == hipSuccess) e = hipMalloc(&d_coef, ncell * nspec * 64 * sizeof(double));
+  if (e != hipSuccess) {
+    cleanup();
+    return srt_set_error(e == hipErrorOutOfMemory ? SRT_ENOMEM : SRT_EDEVICE, "interp model setup: %s", hipGetErrorString(e));
+  }
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(c_tri_ptr), TRI_PTR, sizeof TRI_PTR);
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(c_tri_col), TRI_COL, sizeof TRI_COL);
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(c_tri_val), TRI_VAL, sizeof TRI_VAL);
+  ArrPtrs ap;
+  for (int a = 0; a < 8; ++a) ap.a[a] = d_arr[a];
+  long long npairs = (long long)ncell * nspec;
+  int blocks = (int)(npairs < 262144 ? npairs : 262144);
+  hipLaunchKernelGGL(build_coeffs_kernel, dim3(blocks), dim3(64), 0, 0, g, ap, dx, dy, dz, d_coef, npairs);
+  e = hipDeviceSynchronize();
+  cleanup();
+  if (e != hipSuccess) {
+    (void)hipFree(d_coef);
+    return srt_set_error(SRT_EDEVICE, "coefficient build failed: %s", hipGetErrorString(e));
+  }
+  srt_model *m = new srt_model;
+  m->kind = 3;
+  m->nspec = nspec;
+  m->d_coef = d_coef;
+  m->device_bytes = (int64_t)(ncell * nspec * 64 * sizeof(double));
+  m->interp.coef = d_coef;
+  m->interp.nspec = nspec;
+  m->interp.ax = Axis{bounds[0], dx, nx};
+  m->interp.ay = Axis{bounds[2], dy, ny};
+  m->interp.az = Axis{bounds[4], dz, nz};
+  fill_common(m->cm, nspec, qs, ms, yearday, msec);
+  rc = model_finish(m);
+  if (rc) {
+    srt_model_destroy(m);
+    return rc;
+  }
+  *out = m;
+  return SRT_OK;
+}
+
+extern "C" int srt_model_create_interp_file(const char *gridfile, int yearday, int msec, srt_model **out) {
+  if (!gridfile || !out) return srt_set_error(SRT_EINVAL, "null argument");
+  srt_host::GridFile gf;
+  std::string err;
+  if (!srt_host::read_grid_file(gridfile, gf, err)) return srt_set_error(SRT_EIO, "%s: %s", gridfile, err.c_str());
+  const double *dptr[7];
+  for (int a = 0; a < 7; ++a) dptr[a] = gf.have_derivs ? gf.derivs[a].data() : nullptr;
+  return srt_model_create_interp(gf.nspec, gf.nx, gf.ny, gf.nz, gf.bounds, gf.qs, gf.ms, gf.F.data(),
+                                 gf.have_derivs ? dptr : nullptr, yearday, msec, out);
+}
+
+extern "C" int srt_model_create_scattered_file(const char *, int, int, double, int, int, double, srt_model **) {
+  return srt_set_error(SRT_EINVAL, "scattered model (modelnum=4) is not built yet in this round");
+}
+
+// ------------------------------------------------------------------------------------------ launches
+template <class K, class... Args>
+static void launch_wave_blocks(K kernel, long long n, hipStream_t st, Args... args) {
+  long long blocks = (n + WAVE - 1) / WAVE;
+  hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(WAVE), 0, st, args...);
+}
+
+struct DevBuf {
+  double *p = nullptr;
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+  int alloc(size_t n) { return hipMalloc(&p, n * sizeof(double)) == hipSuccess ? 0 : -1; }
+};
+
+static int upload(DevBuf &b, const double *h, size_t n) {
+  if (b.alloc(n)) return srt_set_error(SRT_ENOMEM, "hipMalloc failed");
+  HIP_OK(hipMemcpy(b.p, h, n * sizeof(double), hipMemcpyHostToDevice));
+  return SRT_OK;
+}
+
+extern "C" int srt_plasma_params(srt_model *m, int64_t n, const double *x, double *qs, double *Ns, double *ms,
+                                 double *nus, double *B0) {
+  if (!m || !x || n < 0) return srt_set_error(SRT_EINVAL, "bad argument");
+  if (n == 0) return SRT_OK;
+  int rc = ensure_init();
+  if (rc) return rc;
+  DevBuf dx, dout;
+  if ((rc = upload(dx, x, 3 * n))) return rc;
+  if (dout.alloc(19 * n)) return srt_set_error(SRT_ENOMEM, "hipMalloc failed");
+  if (m->kind == 1) launch_wave_blocks(params_kernel<NgoModel, false>, n, 0, (const NgoModel *)m->d_model, (const Common *)m->d_common, (long long)n, (const double *)dx.p, dout.p);
+  else if (m->kind == 3) launch_wave_blocks(params_kernel<InterpModel, true>, n, 0, (const InterpModel *)m->d_model, (const Common *)m->d_common, (long long)n, (const double *)dx.p, dout.p);
+  else return srt_set_error(SRT_EINVAL, "model kind %d unsupported", m->kind);
+  std::vector<double> h(19 * n);
+  HIP_OK(hipMemcpy(h.data(), dout.p, h.size() * sizeof(double), hipMemcpyDeviceToHost));
+  for (int64_t i = 0; i < n; ++i) {
+    for (int s = 0; s < 4; ++s) {
+      if (qs) qs[4 * i + s] = h[19 * i + s];
+      if (Ns) Ns[4 * i + s] = h[19 * i + 4 + s];
+      if (ms) ms[4 * i + s] = h[19 * i + 8 + s];
+      if (nus) nus[4 * i + s] = h[19 * i + 12 + s];
+    }
+    if (B0)
+      for (int c = 0; c < 3; ++c) B0[3 * i + c] = h[19 * i + 16 + c];
+  }
+  return SRT_OK;
+}
+
+extern "C" int srt_dispersion(srt_model *m, int64_t n, const double *x, const double *k, const double *w, double *out) {
+  if (!m || !x || !k || !w || !out || n < 0) return srt_set_error(SRT_EINVAL, "bad argument");
+  if (n == 0) return SRT_OK;
+  int rc = ensure_init();
+  if (rc) return rc;
+  DevBuf dx, dk, dw, dout;
+  if ((rc = upload(dx, x, 3 * n)) || (rc = upload(dk, k, 3 * n)) || (rc = upload(dw, w, n))) return rc;
+  if (dout.alloc(10 * n)) return srt_set_error(SRT_ENOMEM, "hipMalloc failed");
+  if (m->kind == 1)
+    launch_wave_blocks(dispersion_kernel<NgoModel, false>, n, 0, (const NgoModel *)m->d_model, (const Common *)m->d_common, (long long)n, (const double *)dx.p, (const double *)dk.p, (const double *)dw.p, dout.p);
+  else if (m->kind == 3)
+    launch_wave_blocks(dispersion_kernel<InterpModel, true>, n, 0, (const InterpModel *)m->d_model, (const Common *)m->d_common, (long long)n, (const double *)dx.p, (const double *)dk.p, (const double *)dw.p, dout.p);
+  else return srt_set_error(SRT_EINVAL, "model kind %d unsupported", m->kind);
+  HIP_OK(hipMemcpy(out, dout.p, 10 * n * sizeof(double), hipMemcpyDeviceToHost));
+  return SRT_OK;
+}
+
+extern "C" int srt_gradients(srt_model *m, int64_t n, const double *x, const double *k, const double *w, double del, double *out) {
+  if (!m || !x || !k || !w || !out || n < 0) return srt_set_error(SRT_EINVAL, "bad argument");
+  if (n == 0) return SRT_OK;
+  int rc = ensure_init();
+  if (rc) return rc;
+  DevBuf dx, dk, dw, dout;
+  if ((rc = upload(dx, x, 3 * n)) || (rc = upload(dk, k, 3 * n)) || (rc = upload(dw, w, n))) return rc;
+  if (dout.alloc(14 * n)) return srt_set_error(SRT_ENOMEM, "hipMalloc failed");
+  if (m->kind == 1)
+    launch_wave_blocks(gradients_kernel<NgoModel, false>, n, 0, (const NgoModel *)m->d_model, (const Common *)m->d_common, (long long)n, (const double *)dx.p, (const double *)dk.p, (const double *)dw.p, del, dout.p);
+  else if (m->kind == 3)
+    launch_wave_blocks(gradients_kernel<InterpModel, true>, n, 0, (const InterpModel *)m->d_model, (const Common *)m->d_common, (long long)n, (const double *)dx.p, (const double *)dk.p, (const double *)dw.p, del, dout.p);
+  else return srt_set_error(SRT_EINVAL, "model kind %d unsupported", m->kind);
+  HIP_OK(hipMemcpy(out, dout.p, 14 * n * sizeof(double), hipMemcpyDeviceToHost));
+  return SRT_OK;
+}
+
+extern "C" int srt_rk_step(srt_model *m, int64_t n, const double *args, const double *dt, double del, double *out) {
+  if (!m || !args || !dt || !out || n < 0) return srt_set_error(SRT_EINVAL, "bad argument");
+  if (n == 0) return SRT_OK;
+  int rc = ensure_init();
+  if (rc) return rc;
+  DevBuf da, dd, dout;
+  if ((rc = upload(da, args, 7 * n)) || (rc = upload(dd, dt, n))) return rc;
+  if (dout.alloc(21 * n)) return srt_set_error(SRT_ENOMEM, "hipMalloc failed");
+  if (m->kind == 1)
+    launch_wave_blocks(rkstep_kernel<NgoModel, false>, n, 0, (const NgoModel *)m->d_model, (const Common *)m->d_common, (long long)n, (const double *)da.p, (const double *)dd.p, del, dout.p);
+  else if (m->kind == 3)
+    launch_wave_blocks(rkstep_kernel<InterpModel, true>, n, 0, (const InterpModel *)m->d_model, (const Common *)m->d_common, (long long)n, (const double *)da.p, (const double *)dd.p, del, dout.p);
+  else return srt_set_error(SRT_EINVAL, "model kind %d unsupported", m->kind);
+  HIP_OK(hipMemcpy(out, dout.p, 21 * n * sizeof(double), hipMemcpyDeviceToHost));
+  return SRT_OK;
+}
+
+// ------------------------------------------------------------------------------------------ hot path
+extern "C" int32_t srt_rows_per_ray(const srt_params *p) {
+  if (!p || p->maxsteps < 1) return 0;
+  int per = p->outputper < 1 ? 1 : p->outputper;
+  return (p->maxsteps + per - 1) / per;
+}
+
+static int check_params(const srt_params *p) {
+  if (!p) return srt_set_error(SRT_EINVAL, "null params");
+  if (p->maxsteps < 1) return srt_set_error(SRT_EINVAL, "maxsteps must be >= 1");
+  if (p->root != 1 && p->root != 2) return srt_set_error(SRT_EINVAL, "root must be 1 or 2");
+  if (!(p->del > 0.0)) return srt_set_error(SRT_EINVAL, "del must be > 0");
+  return SRT_OK;
+}
+
+extern "C" int srt_trace_batch_device(srt_model *m, const srt_params *p, int64_t nrays, const double *d_pos0,
+                                      const double *d_dir0, const double *d_w0, double *d_rows, int32_t *d_nrows,
+                                      int32_t *d_stopcond, int64_t *d_counters, void *stream) {
+  if (!m || !d_pos0 || !d_dir0 || !d_w0 || !d_rows || !d_nrows || !d_stopcond || !d_counters || nrays < 0)
+    return srt_set_error(SRT_EINVAL, "bad argument");
+  int rc = check_params(p);
+  if (rc) return rc;
+  if ((rc = ensure_init())) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  TraceArgs a;
+  a.pos0 = d_pos0;
+  a.dir0 = d_dir0;
+  a.w0 = d_w0;
+  a.nrays = nrays;
+  a.rows = d_rows;
+  a.nrows = d_nrows;
+  a.stopcond = d_stopcond;
+  a.counters = (unsigned long long *)d_counters;
+  a.p.dt0 = p->dt0; a.p.dtmax = p->dtmax; a.p.tmax = p->tmax; a.p.maxerr = p->maxerr;
+  a.p.minalt = p->minalt; a.p.del = p->del;
+  a.p.maxsteps = p->maxsteps; a.p.root = p->root; a.p.fixedstep = p->fixedstep;
+  a.p.outputper = p->outputper < 1 ? 1 : p->outputper;
+  a.p.first_attempt_policy = p->first_attempt_policy;
+  a.p.refill_threshold = p->refill_threshold;
+  a.p.slots = srt_rows_per_ray(p);
+  HIP_OK(hipMemsetAsync(d_counters, 0, 4 * sizeof(int64_t), st));
+  // persistent grid: enough one-wave blocks to fill the chip, never more than the rays need
+  long long want = (nrays + WAVE - 1) / WAVE;
+  int per_cu = (m->kind == 3) ? 4 : 8; // interp: 33 KB LDS tile per wave
+  long long grid = (long long)m->cu_count * per_cu;
+  if (grid > want) grid = want;
+  if (grid < 1) grid = 1;
+  HIP_OK(hipEventRecord(m->ev0, st));
+  bool fixed = p->fixedstep != 0;
+  if (m->kind == 1) {
+    if (fixed) hipLaunchKernelGGL((trace_kernel<NgoModel, true, false>), dim3((unsigned)grid), dim3(WAVE), 0, st, (const NgoModel *)m->d_model, (const Common *)m->d_common, a);
+    else hipLaunchKernelGGL((trace_kernel<NgoModel, false, false>), dim3((unsigned)grid), dim3(WAVE), 0, st, (const NgoModel *)m->d_model, (const Common *)m->d_common, a);
+  } else if (m->kind == 3) {
+    if (fixed) hipLaunchKernelGGL((trace_kernel<InterpModel, true, true>), dim3((unsigned)grid), dim3(WAVE), 0, st, (const InterpModel *)m->d_model, (const Common *)m->d_common, a);
+    else hipLaunchKernelGGL((trace_kernel<InterpModel, false, true>), dim3((unsigned)grid), dim3(WAVE), 0, st, (const InterpModel *)m->d_model, (const Common *)m->d_common, a);
+  } else {
+    return srt_set_error(SRT_EINVAL, "model kind %d unsupported", m->kind);
+  }
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipEventRecord(m->ev1, st));
+  m->timed = true;
+  return SRT_OK;
+}
+
+extern "C" int srt_last_kernel_ms(srt_model *m, float *ms) {
+  if (!m || !ms) return srt_set_error(SRT_EINVAL, "null argument");
+  if (!m->timed) return srt_set_error(SRT_EINVAL, "no trace launched on this model yet");
+  HIP_OK(hipEventSynchronize(m->ev1));
+  HIP_OK(hipEventElapsedTime(ms, m->ev0, m->ev1));
+  return SRT_OK;
+}
+
+// AoS [n][3] -> SoA [3][n]
+__global__ void aos_to_soa3(const double *in, double *out, long long n) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    out[i] = in[3 * i];
+    out[n + i] = in[3 * i + 1];
+    out[2 * n + i] = in[3 * i + 2];
+  }
+}
+
+extern "C" int srt_trace_batch(srt_model *m, const srt_params *p, int64_t nrays, const double *pos0,
+                               const double *dir0, const double *w0, double *rows, int32_t *nrows,
+                               int32_t *stopcond, int64_t *accepted_steps) {
+  if (!m || !pos0 || !dir0 || !w0 || !rows || !nrows || !stopcond || nrays < 0) return srt_set_error(SRT_EINVAL, "bad argument");
+  int rc = check_params(p);
+  if (rc) return rc;
+  if (nrays == 0) {
+    if (accepted_steps) *accepted_steps = 0;
+    return SRT_OK;
+  }
+  if ((rc = ensure_init())) return rc;
+  const int slots = srt_rows_per_ray(p);
+  const size_t nrow_d = (size_t)nrays * slots * SRT_ROW;
+  DevBuf a_pos, a_dir, s_pos, s_dir, dw, drows;
+  if ((rc = upload(a_pos, pos0, 3 * nrays)) || (rc = upload(a_dir, dir0, 3 * nrays)) || (rc = upload(dw, w0, nrays))) return rc;
+  if (s_pos.alloc(3 * nrays) || s_dir.alloc(3 * nrays) || drows.alloc(nrow_d)) return srt_set_error(SRT_ENOMEM, "hipMalloc failed (rows: %zu bytes)", nrow_d * 8);
+  int32_t *d_n = nullptr, *d_s = nullptr;
+  int64_t *d_c = nullptr;
+  auto freeall = [&]() {
+    if (d_n) (void)hipFree(d_n);
+    if (d_s) (void)hipFree(d_s);
+    if (d_c) (void)hipFree(d_c);
+  };
+  if (hipMalloc(&d_n, nrays * sizeof(int32_t)) != hipSuccess || hipMalloc(&d_s, nrays * sizeof(int32_t)) != hipSuccess ||
+      hipMalloc(&d_c, 4 * sizeof(int64_t)) != hipSuccess) {
+    freeall();
+    return srt_set_error(SRT_ENOMEM, "hipMalloc failed");
+  }
+  unsigned blocks = (unsigned)((nrays + 255) / 256);
+  hipLaunchKernelGGL(aos_to_soa3, dim3(blocks), dim3(256), 0, 0, (const double *)a_pos.p, s_pos.p, (long long)nrays);
+  hipLaunchKernelGGL(aos_to_soa3, dim3(blocks), dim3(256), 0, 0, (const double *)a_dir.p, s_dir.p, (long long)nrays);
+  (void)hipMemsetAsync(drows.p, 0, nrow_d * sizeof(double), 0);
+  rc = srt_trace_batch_device(m, p, nrays, s_pos.p, s_dir.p, dw.p, drows.p, d_n, d_s, d_c, nullptr);
+  if (rc == SRT_OK) {
+    hipError_t e = hipMemcpy(rows, drows.p, nrow_d * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(nrows, d_n, nrays * sizeof(int32_t), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(stopcond, d_s, nrays * sizeof(int32_t), hipMemcpyDeviceToHost);
+    int64_t c[4] = {0, 0, 0, 0};
+    if (e == hipSuccess) e = hipMemcpy(c, d_c, sizeof c, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = srt_set_error(SRT_EDEVICE, "trace kernel failed: %s", hipGetErrorString(e));
+    else if (accepted_steps) *accepted_steps = c[1];
+  }
+  freeall();
+  return rc;
+}

@@ -1,0 +1,281 @@
+// srt_device.hpp -- device-side physics of the many-ray Haselgrove integrator (gfx950 / CDNA4).
+//
+// One ray per lane.  Everything here is fp64 VALU work; there is no dense contraction on this path,
+// so no MFMA.  The functions restate WHAT the reference computes (file:line cited per function) but
+// are organised for the GPU: common sub-expressions that the Fortran re-evaluates per call
+// (Stix parameters shared by the six F evaluations of dF/dk, the plasma state shared by dF/dk and
+// dF/dw, trigonometry in the dipole field) are evaluated once, and divisions are merged.  Results
+// differ from the reference at rounding level only; the parity ladder in DESIGN.md bounds that.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace srt {
+
+constexpr double EPS0 = 8.854187817e-12;          // constants.f95:4
+constexpr double PI = 3.141592653589793238462643; // constants.f95:5
+constexpr double R_E = 6371.2e3;                  // constants.f95:8
+constexpr int MAXSPEC = 4;
+constexpr int ROW = 20;
+
+// Per-model species constants (qs, ms of funcPlasmaParams; constant in all three adapters).
+struct Species {
+  double q[MAXSPEC], m[MAXSPEC];
+  double c[MAXSPEC]; // q^2/(m eps0):   wps2 = Ns * c      (raytracer.f95:92)
+  double g[MAXSPEC]; // q/m:            wcs  = g * |B0|    (raytracer.f95:93)
+  double maxq2;      // maxval(abs(qs))**2                  (raytracer.f95:65)
+  double minm_eps0;  // minval(ms)*EPS0
+  int nspec;
+};
+
+// Dipole field + SM<->GSM round trip constants (bmodel_dipole.f95, xform_double/T4.f95).
+struct FieldConst {
+  double bo_re3; // Bo * R_E^3, Bo = .312/10000 T
+  double cm, sm; // cos(mu), sin(mu), mu = dipole tilt for the run's itime
+};
+
+struct Common {
+  Species sp;
+  FieldConst fld;
+  double C; // speed of light as constants.f95:7 computes it
+};
+
+// ---------------------------------------------------------------------------------------------
+// Dipole B in SM coordinates, then the adapters' GSM round trip through float32 nT
+// (bmodel_dipole.f95:20-48; interp_dens_model_adapter.f95:243-267 and its twins; SURVEY A-8).
+// Trig-free form: B = Bo R_E^3 / r^5 * (-3xz, -3yz, x^2 + y^2 - 2 z^2).
+__device__ __forceinline__ void bfield(const FieldConst &f, double x, double y, double z, double B[3]) {
+  double rho2 = x * x + y * y;
+  double r2 = rho2 + z * z;
+  double r = sqrt(r2);
+  double k = f.bo_re3 / (r2 * r2 * r);
+  double bx = -3.0 * k * x * z;
+  double by = -3.0 * k * y * z;
+  double bz = k * (rho2 - 2.0 * z * z);
+  // SM -> GSM: rotate about y by -mu
+  double gx = bx * f.cm - bz * f.sm;
+  double gz = bz * f.cm + bx * f.sm;
+  // B0xBASE = real(1.0e9_DP*B0tmp2(1)); B0tmp = (B0xBASE + 0.0)*1.0e-9_DP
+  gx = (double)((float)(1.0e9 * gx)) * 1.0e-9;
+  double gy = (double)((float)(1.0e9 * by)) * 1.0e-9;
+  gz = (double)((float)(1.0e9 * gz)) * 1.0e-9;
+  // GSM -> SM: rotate about y by +mu
+  B[0] = gx * f.cm + gz * f.sm;
+  B[1] = gy;
+  B[2] = gz * f.cm - gx * f.sm;
+}
+
+// ---------------------------------------------------------------------------------------------
+// stix_parameters (raytracer.f95:81-102) + the products dispersion_relation needs.
+struct Stix {
+  double S, D, P, R, L;
+  double RL, PS, RLP;
+  bool freespace; // raytracer.f95:65 (mis-parenthesised threshold, SURVEY A-5)
+};
+
+__device__ __forceinline__ Stix stix_parameters(const Species &sp, double w, const double Ns[MAXSPEC],
+                                                double Bmag) {
+  double sr = 0.0, sl = 0.0, sw = 0.0, maxN = 0.0;
+#pragma unroll
+  for (int s = 0; s < MAXSPEC; ++s) {
+    double wps2 = Ns[s] * sp.c[s];
+    double wcs = sp.g[s] * Bmag;
+    double a = w + wcs, b = w - wcs;
+    double t = wps2 / (w * a * b); // one division serves both the R and the L term
+    sr += t * b;                   // wps2/(w*(w+wcs))
+    sl += t * a;                   // wps2/(w*(w-wcs))
+    sw += wps2;
+    maxN = fmax(maxN, Ns[s]);
+  }
+  Stix st;
+  st.R = 1.0 - sr;
+  st.L = 1.0 - sl;
+  st.P = 1.0 - sw / (w * w);
+  st.S = 0.5 * (st.R + st.L);
+  st.D = 0.5 * (st.R - st.L);
+  st.RL = st.R * st.L;
+  st.PS = st.P * st.S;
+  st.RLP = st.RL * st.P;
+  // w > 100*sqrt(maxN*maxq^2)/(minm*eps0)
+  double lhs = w * sp.minm_eps0 * 0.01;
+  st.freespace = (lhs * lhs > maxN * sp.maxq2) && lhs > 0.0;
+  return st;
+}
+
+// dispersion_relation (raytracer.f95:41-72) for refractive index n, given the Stix parameters.
+__device__ __forceinline__ double dispersion_F(const Stix &st, const double n[3], const double B[3],
+                                               double B2) {
+  double nmag2 = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
+  double nb = n[0] * B[0] + n[1] * B[1] + n[2] * B[2];
+  double cos2 = (nb * nb) / (nmag2 * B2);
+  double sin2 = 1.0 - cos2;
+  double A = st.S * sin2 + st.P * cos2;
+  double Bq = st.RL * sin2 + st.PS * (1.0 + cos2);
+  double F = A * (nmag2 * nmag2) - Bq * nmag2 + st.RLP;
+  return st.freespace ? (1.0 - nmag2) : F;
+}
+
+__device__ __forceinline__ double fd_step(double del, double v) {
+  double a = del * fabs(v);
+  return (a > del) ? a : del; // max(del*abs(v), del)  (raytracer.f95:139,192,239)
+}
+
+// dispersion_relation_dFdk with del = 1e-8 (raytracer.f95:118-155), plasma state given.
+__device__ __forceinline__ void dFdk(const Stix &st, const double k[3], double cw /* C/w */,
+                                     const double B[3], double B2, double out[3]) {
+  const double del = 1.0e-8;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    double d = fd_step(del, k[c]);
+    double np[3] = {k[0] * cw, k[1] * cw, k[2] * cw};
+    double nm[3] = {np[0], np[1], np[2]};
+    np[c] = (k[c] + d) * cw;
+    nm[c] = (k[c] - d) * cw;
+    out[c] = (dispersion_F(st, np, B, B2) - dispersion_F(st, nm, B, B2)) / d * 0.5;
+  }
+}
+
+// dispersion_relation_dFdw with del = 1e-8 (raytracer.f95:172-198).
+__device__ __forceinline__ double dFdw(const Species &sp, const double k[3], double w, double C,
+                                       const double Ns[MAXSPEC], const double B[3], double B2,
+                                       double Bmag) {
+  const double del = 1.0e-8;
+  double d = fd_step(del, w);
+  double wp = w + d, wm = w - d;
+  Stix sp_ = stix_parameters(sp, wp, Ns, Bmag);
+  Stix sm_ = stix_parameters(sp, wm, Ns, Bmag);
+  double cp = C / wp, cm = C / wm;
+  double np[3] = {k[0] * cp, k[1] * cp, k[2] * cp};
+  double nm[3] = {k[0] * cm, k[1] * cm, k[2] * cm};
+  return (dispersion_F(sp_, np, B, B2) - dispersion_F(sm_, nm, B, B2)) / d * 0.5;
+}
+
+// ---------------------------------------------------------------------------------------------
+// is_right_handed (raytracer.f95:355-405) without the complex SVD.
+//
+// The reference builds M = [[a,-iD,b],[iD,c,0],[b,0,d]] (entries rounded to float32 by default-kind
+// cmplx, phi passed in DEGREES to cos/sin -- SURVEY A-4), takes E = row 3 of V^H from zgesvd and tests
+// the x-y rotation sense from Re(E) to Re(iE).  M is unitarily similar to the real symmetric
+// T = [[a,D,b],[D,c,0],[b,0,d]]; with lambda = eigenvalue of T of least magnitude the test equals
+// .not.( D/(c-lambda) > 0 ).  Eigenvalues by fixed-sweep cyclic Jacobi, fully unrolled on scalars.
+__device__ __forceinline__ void jacobi_rot(double &app, double &aqq, double &apq, double &arp, double &arq) {
+  // annihilate apq; r is the third index
+  if (apq != 0.0) {
+    double theta = (aqq - app) / (2.0 * apq);
+    double t = copysign(1.0, theta) / (fabs(theta) + sqrt(theta * theta + 1.0));
+    double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
+    app = app - t * apq;
+    aqq = aqq + t * apq;
+    apq = 0.0;
+    double nrp = cs * arp - sn * arq;
+    double nrq = sn * arp + cs * arq;
+    arp = nrp;
+    arq = nrq;
+  }
+}
+
+__device__ inline bool is_right_handed(double n2, double phi_deg, double S, double D, double P) {
+  double sp, cp;
+  sincos(phi_deg, &sp, &cp); // degrees fed to cos/sin, as the reference does (raytracer.f95:450 -> :361)
+  double a00 = (double)(float)(S - n2 * (cp * cp));
+  double a01 = (double)(float)(D);
+  double a02 = (double)(float)(n2 * cp * sp);
+  double a11 = (double)(float)(S - n2);
+  double a12 = 0.0;
+  double a22 = (double)(float)(P - n2 * (sp * sp));
+  const double c = a11, Dm = a01;
+#pragma unroll 1
+  for (int sweep = 0; sweep < 8; ++sweep) {
+    jacobi_rot(a00, a11, a01, a02, a12); // (p,q)=(0,1), r=2
+    jacobi_rot(a00, a22, a02, a01, a12); // (0,2), r=1
+    jacobi_rot(a11, a22, a12, a01, a02); // (1,2), r=0
+  }
+  double lam = a00;
+  if (fabs(a11) < fabs(lam)) lam = a11;
+  if (fabs(a22) < fabs(lam)) lam = a22;
+  return !(Dm / (c - lam) > 0.0);
+}
+
+// solve_dispersion_relation (raytracer.f95:408-502): complex roots k1, k2 (re, im) along direction k.
+struct Roots {
+  double k1re, k1im, k2re, k2im;
+};
+__device__ __forceinline__ void csqrt_real_or_imag(double re, double im, double &ore, double &oim) {
+  // principal square root of re + i*im
+  if (im == 0.0) {
+    if (re >= 0.0) {
+      ore = sqrt(re);
+      oim = 0.0;
+    } else {
+      ore = 0.0;
+      oim = sqrt(-re);
+    }
+    return;
+  }
+  double m = hypot(re, im);
+  double a = sqrt(0.5 * (m + fabs(re)));
+  double b = im / (2.0 * a);
+  if (re >= 0.0) {
+    ore = a;
+    oim = b;
+  } else {
+    ore = fabs(b);
+    oim = copysign(a, im);
+  }
+}
+__device__ inline Roots solve_dispersion(const Common &cm, const double kdir[3], double w,
+                                         const double Ns[MAXSPEC], const double B[3]) {
+  double B2 = B[0] * B[0] + B[1] * B[1] + B[2] * B[2];
+  double kb = kdir[0] * B[0] + kdir[1] * B[1] + kdir[2] * B[2];
+  double kk = kdir[0] * kdir[0] + kdir[1] * kdir[1] + kdir[2] * kdir[2];
+  double cos2 = (kb * kb) / (kk * B2);
+  double sin2 = 1.0 - cos2;
+  // The reference lets cos2 exceed 1 by rounding and dies in zgesvd on the NaN (SURVEY A-2); clamp.
+  double phi = acos(sqrt(fmin(cos2, 1.0))) * (180.0 / PI);
+  Stix st = stix_parameters(cm.sp, w, Ns, sqrt(B2));
+  double A = st.S * sin2 + st.P * cos2;
+  double Bq = st.RL * sin2 + st.PS * (1.0 + cos2);
+  double disc = Bq * Bq - 4.0 * A * st.RLP;
+  double sre, sim;
+  csqrt_real_or_imag(disc, 0.0, sre, sim);
+  double inv2A = 1.0 / (2.0 * A);
+  double q1re = (Bq + sre) * inv2A, q1im = sim * inv2A;
+  double q2re = (Bq - sre) * inv2A, q2im = -sim * inv2A;
+  double n1re, n1im, n2re, n2im;
+  csqrt_real_or_imag(q1re, q1im, n1re, n1im);
+  csqrt_real_or_imag(q2re, q2im, n2re, n2im);
+  double wc = w / cm.C;
+  Roots r;
+  bool swap = (n1re > 0.0) && is_right_handed(q1re, phi, st.S, st.D, st.P);
+  if (swap) {
+    r.k1re = wc * n2re; r.k1im = wc * n2im; r.k2re = wc * n1re; r.k2im = wc * n1im;
+  } else {
+    r.k1re = wc * n1re; r.k1im = wc * n1im; r.k2re = wc * n2re; r.k2im = wc * n2im;
+  }
+  return r;
+}
+
+// raytracer_stopconditions (raytracer.f95:324-353)
+__device__ __forceinline__ int stop_conditions(const double x[6], const double vg[3], double dt, int nstep,
+                                               int maxsteps, double minalt) {
+  if (sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]) < minalt) return 1;
+  if (sqrt(x[3] * x[3] + x[4] * x[4] + x[5] * x[5]) == 0.0) return 2;
+  if (sqrt(vg[0] * vg[0] + vg[1] * vg[1] + vg[2] * vg[2]) > 1.0 + 1e-2) return 3;
+  if (dt < (double)1e-14f) return 5;
+  if (nstep >= maxsteps) return 6;
+  return 0;
+}
+
+// RKF45 tableau (raytracer.f95:8-27)
+namespace rkf {
+constexpr double a21 = 1.0 / 4.0;
+constexpr double a31 = 3.0 / 32.0, a32 = 9.0 / 32.0;
+constexpr double a41 = 1932.0 / 2197.0, a42 = -7200.0 / 2197.0, a43 = 7296.0 / 2197.0;
+constexpr double a51 = 439.0 / 216.0, a52 = -8.0, a53 = 3680.0 / 513.0, a54 = -845.0 / 4104.0;
+constexpr double a61 = -8.0 / 27.0, a62 = 2.0, a63 = -3544.0 / 2565.0, a64 = 1859.0 / 4104.0, a65 = -11.0 / 40.0;
+constexpr double b41 = 25.0 / 216.0, b43 = 1408.0 / 2565.0, b44 = 2197.0 / 4104.0, b45 = -1.0 / 5.0;
+constexpr double b51 = 16.0 / 135.0, b53 = 6656.0 / 12825.0, b54 = 28561.0 / 56430.0, b55 = -9.0 / 50.0,
+                 b56 = 2.0 / 55.0;
+} // namespace rkf
+
+} // namespace srt

@@ -1,0 +1,237 @@
+// srt_host.cpp -- host-side file formats of the drop-in boundary (no device code).
+#include "srt_host.hpp"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "../../include/srt.h"
+
+int srt_set_error(int code, const char *fmt, ...);
+
+namespace srt_host {
+
+// ---------------------------------------------------------------------------------------------
+// xform_double: get_q_c_d (Get_q_c.f95:4-30) -> t1_d inverse (T1.f95) -> t2_d (T2.f95) -> mu (T4.f95)
+static void rot_x(double a, const double in[3], double out[3]) {
+  double c = cos(a), s = sin(a);
+  out[0] = in[0]; out[1] = in[1] * c + in[2] * s; out[2] = in[2] * c - in[1] * s;
+}
+static void rot_z(double a, const double in[3], double out[3]) {
+  double c = cos(a), s = sin(a);
+  out[0] = in[0] * c + in[1] * s; out[1] = in[1] * c - in[0] * s; out[2] = in[2];
+}
+double dipole_tilt(int yearday, int msec) {
+  const double degrad = 3.141592653589793238462643 / 180.0;
+  int iyr = yearday / 1000, iday = yearday - iyr * 1000;
+  double ut = msec / 3600000.0, fracday = ut / 24.0;
+  double rmjd = 45.0 + (double)(iyr - 1859) * 365.0 + ((double)((iyr - 1861) / 4) + 1.0) + (double)iday - 1.0 + fracday;
+  double factor = (rmjd - 46066.0) / 365.25;
+  double phi = (78.8 + 4.283e-2 * factor) * degrad;
+  double lamda = (289.1 - 1.413e-2 * factor) * degrad;
+  double qg[3] = {cos(phi) * cos(lamda), cos(phi) * sin(lamda), sin(phi)};
+  double t0 = (rmjd - 51544.5) / 36525.0; // T0.f95
+  double theta = (100.461 + 36000.770 * t0 + 15.04107 * ut) * degrad;
+  double tmp[3], tmp2[3], qc[3];
+  rot_z(-theta, qg, tmp);
+  double eps = (23.439 - 0.013 * t0) * degrad;
+  double m = (357.528 + 35999.05 * t0 + 0.04107 * ut) * degrad;
+  double cg = 280.46 + 36000.772 * t0 + 0.04107 * ut;
+  double lamdas = (cg + (1.915 - 0.0048 * t0) * sin(m) + 0.02 * sin(2.0 * m)) * degrad;
+  rot_x(eps, tmp, tmp2);
+  rot_z(lamdas, tmp2, qc);
+  return -atan(qc[0] / sqrt(qc[1] * qc[1] + qc[2] * qc[2]));
+}
+
+// ---------------------------------------------------------------------------------------------
+ListReader::ListReader(const char *path) : f_(fopen(path, "r")), line_(1 << 16) {}
+ListReader::~ListReader() {
+  if (f_) fclose((FILE *)f_);
+}
+int64_t ListReader::read(int64_t n, double *out) {
+  int64_t got = 0;
+  FILE *f = (FILE *)f_;
+  while (got < n) {
+    if (!fgets(line_.data(), (int)line_.size(), f)) return got;
+    char *s = line_.data();
+    while (got < n) {
+      while (*s == ' ' || *s == '\t' || *s == ',' || *s == '\r' || *s == '\n') ++s;
+      if (!*s) break;
+      char *e = s;
+      // accept Fortran 'd' exponents
+      char tok[64];
+      int k = 0;
+      while (*e && *e != ' ' && *e != '\t' && *e != ',' && *e != '\r' && *e != '\n' && k < 63) {
+        char ch = *e++;
+        tok[k++] = (ch == 'd' || ch == 'D') ? 'e' : ch;
+      }
+      tok[k] = 0;
+      char *endp = nullptr;
+      double v = strtod(tok, &endp);
+      if (endp == tok) return got; // not a number
+      out[got++] = v;
+      s = e;
+    }
+  }
+  return got;
+}
+
+bool read_newray(const char *path, NgoConfig &c, std::string &err) {
+  ListReader r(path);
+  if (!r.ok()) {
+    err = "cannot open";
+    return false;
+  }
+  double v[16];
+  if (r.read(4, v) != 4) { err = "card 1 (intera numres nsuppr spelat) incomplete"; return false; }
+  for (;;) { // satellite coordinates until distre <= -1 (:64-80)
+    if (r.read(2, v) != 2) { err = "unterminated satellite-coordinate list"; return false; }
+    c.last_latitu = v[1];
+    if (v[0] <= -1.0) break;
+  }
+  if (r.read(10, v) != 10) { err = "model card (num kskip mode kount kducts ktape refalt dsrrng dsrlat dsdens) incomplete"; return false; }
+  c.num = (int)v[0];
+  c.kducts = (int)v[4];
+  c.dsrrng = v[7]; c.dsrlat = v[8]; c.dsdens = v[9];
+  if (c.num < 2 || c.num > 4) { err = "num must be 2..4"; return false; }
+  if (c.kducts < 0 || c.kducts > 9) { err = "kducts must be 0..9"; return false; }
+  if (r.read(5, v) != 5) { err = "card egfeq therm hm absb relb incomplete"; return false; }
+  c.therm = v[1];
+  if (r.read(5, v) != 5) { err = "card rbase ane0 alpha0(2:4) incomplete"; return false; }
+  c.rbase = v[0]; c.ane0 = v[1]; c.alpha0[2] = v[2]; c.alpha0[3] = v[3]; c.alpha0[4] = v[4];
+  if (r.read(5, v) != 5) { err = "card rzero scbot rstop rdiv hmin incomplete"; return false; }
+  c.rzero = v[0]; c.scbot = v[1];
+  if (c.kducts >= 1) {
+    if (r.read(5, v) != 5) { err = "plasmapause card (lk expk ddk rconsn scr) incomplete"; return false; }
+    c.lk = v[0]; c.expk = v[1]; c.ddk = v[2]; c.rconsn = v[3]; c.scr = v[4];
+    for (int k = 2; k <= c.kducts; ++k) {
+      if (r.read(12, v) != 12) { err = "duct card incomplete"; return false; }
+      c.l0[k] = v[0]; c.def[k] = v[1]; c.dd[k] = v[2];
+      c.rducln[k] = v[3]; c.hducln[k] = v[4]; c.rducun[k] = v[5]; c.hducun[k] = v[6];
+      c.rducls[k] = v[7]; c.hducls[k] = v[8]; c.rducus[k] = v[9]; c.hducus[k] = v[10];
+      c.sidedu[k] = v[11];
+    }
+  }
+  return true;
+}
+
+bool read_grid_file(const char *path, GridFile &g, std::string &err) {
+  ListReader r(path);
+  if (!r.ok()) { err = "cannot open"; return false; }
+  double v[8];
+  if (r.read(5, v) != 5) { err = "size header incomplete"; return false; }
+  g.compder = (int)v[0]; g.nspec = (int)v[1]; g.nx = (int)v[2]; g.ny = (int)v[3]; g.nz = (int)v[4];
+  if (g.nspec < 1 || g.nspec > 4) { err = "nspec must be 1..4"; return false; }
+  if (g.nx < 2 || g.ny < 2 || g.nz < 2) { err = "grid needs >= 2 nodes per axis"; return false; }
+  if (r.read(6, g.bounds) != 6) { err = "bounds incomplete"; return false; }
+  if (r.read(g.nspec, g.qs) != g.nspec) { err = "charges incomplete"; return false; }
+  if (r.read(g.nspec, g.ms) != g.nspec) { err = "masses incomplete"; return false; }
+  size_t nnode = (size_t)g.nx * g.ny * g.nz, n = nnode * g.nspec;
+  g.F.resize(n);
+  for (size_t c = 0; c < nnode; ++c) // one record per node (:100-106)
+    if (r.read(g.nspec, g.F.data() + c * g.nspec) != g.nspec) { err = "grid values truncated"; return false; }
+  g.have_derivs = (g.compder == 1);
+  if (g.have_derivs)
+    for (int a = 0; a < 7; ++a) {
+      g.derivs[a].resize(n);
+      if (r.read((int64_t)n, g.derivs[a].data()) != (int64_t)n) { err = "derivative block truncated"; return false; }
+    }
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+void format_es24(double v, char out[25]) {
+  char tmp[64];
+  if (std::isnan(v)) {
+    snprintf(out, 25, "%24s", "NaN");
+    return;
+  }
+  if (std::isinf(v)) {
+    snprintf(out, 25, "%24s", v > 0 ? "Inf" : "-Inf");
+    return;
+  }
+  snprintf(tmp, sizeof tmp, "%.15E", v); // d.dddddddddddddddE+XX
+  char *e = strchr(tmp, 'E');
+  int ex = atoi(e + 1);
+  *e = 0;
+  char buf[64];
+  snprintf(buf, sizeof buf, "%sE%c%03d", tmp, ex < 0 ? '-' : '+', ex < 0 ? -ex : ex);
+  snprintf(out, 25, "%24s", buf);
+}
+
+} // namespace srt_host
+
+// ================================================================================ C ABI (file I/O)
+extern "C" void srt_free(void *p) { free(p); }
+
+extern "C" int64_t srt_read_rays_file(const char *path, double **pos0, double **dir0, double **w0) {
+  if (!path || !pos0 || !dir0 || !w0) return srt_set_error(SRT_EINVAL, "null argument");
+  srt_host::ListReader r(path);
+  if (!r.ok()) return srt_set_error(SRT_EIO, "%s: cannot open", path);
+  std::vector<double> all;
+  double v[7];
+  while (r.read(7, v) == 7) all.insert(all.end(), v, v + 7); // read(infile,*) pos0, dir0, w ; EOF ends (driver:1146)
+  int64_t n = (int64_t)(all.size() / 7);
+  *pos0 = (double *)malloc(sizeof(double) * 3 * (n ? n : 1));
+  *dir0 = (double *)malloc(sizeof(double) * 3 * (n ? n : 1));
+  *w0 = (double *)malloc(sizeof(double) * (n ? n : 1));
+  for (int64_t i = 0; i < n; ++i) {
+    for (int c = 0; c < 3; ++c) {
+      (*pos0)[3 * i + c] = all[7 * i + c];
+      (*dir0)[3 * i + c] = all[7 * i + 3 + c];
+    }
+    (*w0)[i] = all[7 * i + 6];
+  }
+  return n;
+}
+
+// record format of raytracer_driver.f95:1197-1217:
+//   (i10, i10, 17es24.15e3, i10) raynum, stopcond, t, pos, vprel, vgrel, n, B0, w, nspec
+//   then nspec x es24.15e3 for each of qs, ms, Ns, nus
+extern "C" int srt_write_ray_file(const char *path, int append, int64_t raynum0, int64_t nrays, const srt_params *p,
+                                  const srt_model *m, const double *w0, const double *rows, const int32_t *nrows,
+                                  const int32_t *stopcond) {
+  if (!path || !p || !m || !w0 || !rows || !nrows || !stopcond) return srt_set_error(SRT_EINVAL, "null argument");
+  FILE *f = fopen(path, append ? "a" : "w");
+  if (!f) return srt_set_error(SRT_EIO, "%s: cannot open for writing", path);
+  std::vector<char> big(1 << 22);
+  setvbuf(f, big.data(), _IOFBF, big.size());
+  const int slots = srt_rows_per_ray(p);
+  const int per = p->outputper < 1 ? 1 : p->outputper;
+  const int nspec = srt_model_nspec(m);
+  double qs[4], ms[4];
+  srt_model_species(m, qs, ms);
+  char qsbuf[4][25], msbuf[4][25], zero[25], num[25];
+  for (int s = 0; s < nspec; ++s) {
+    srt_host::format_es24(qs[s], qsbuf[s]);
+    srt_host::format_es24(ms[s], msbuf[s]);
+  }
+  srt_host::format_es24(0.0, zero);
+  for (int64_t r = 0; r < nrays; ++r) {
+    int kept = (nrows[r] + per - 1) / per;
+    if (kept > slots) kept = slots;
+    char wbuf[25];
+    srt_host::format_es24(w0[r], wbuf);
+    for (int s = 0; s < kept; ++s) {
+      const double *row = rows + ((size_t)r * slots + s) * SRT_ROW;
+      fprintf(f, "%10lld%10d", (long long)(raynum0 + r), (int)stopcond[r]);
+      for (int c = 0; c < 16; ++c) {
+        srt_host::format_es24(row[c], num);
+        fputs(num, f);
+      }
+      fputs(wbuf, f);
+      fprintf(f, "%10d", nspec);
+      for (int k = 0; k < nspec; ++k) fputs(qsbuf[k], f);
+      for (int k = 0; k < nspec; ++k) fputs(msbuf[k], f);
+      for (int k = 0; k < nspec; ++k) {
+        srt_host::format_es24(row[16 + k], num);
+        fputs(num, f);
+      }
+      for (int k = 0; k < nspec; ++k) fputs(zero, f);
+      fputc('\n', f);
+    }
+  }
+  fclose(f);
+  return SRT_OK;
+}

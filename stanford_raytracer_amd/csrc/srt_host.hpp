@@ -1,0 +1,50 @@
+// srt_host.hpp -- host-side helpers of libsrt_hip: file formats of the boundary and run constants.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace srt_host {
+
+// dipole tilt angle mu of xform_double/T4.f95:7-18 for itime = (yearday, msec)
+double dipole_tilt(int yearday, int msec);
+
+// newray.in card file (ngo_dens_model.f95:45-118; field names per matlab/unused/parse_newray_cards.m)
+struct NgoConfig {
+  int num = 0, kducts = 0;
+  double dsrrng = 0, dsrlat = 0, dsdens = 0, last_latitu = 0;
+  double therm = 0, rbase = 0, ane0 = 0, alpha0[5] = {0, 0, 0, 0, 0}, rzero = 0, scbot = 0;
+  double lk = 0, expk = 0, ddk = 0, rconsn = 0, scr = 0;
+  double l0[10] = {0}, def[10] = {0}, dd[10] = {0}, rducln[10] = {0}, hducln[10] = {0}, rducun[10] = {0},
+         hducun[10] = {0}, rducls[10] = {0}, hducls[10] = {0}, rducus[10] = {0}, hducus[10] = {0}, sidedu[10] = {0};
+};
+bool read_newray(const char *path, NgoConfig &cfg, std::string &err);
+
+// model-3 grid file (interp_dens_model_adapter.f95:58-117)
+struct GridFile {
+  int compder = 0, nspec = 0, nx = 0, ny = 0, nz = 0;
+  bool have_derivs = false;
+  double bounds[6] = {0}, qs[4] = {0}, ms[4] = {0};
+  std::vector<double> F;
+  std::vector<double> derivs[7];
+};
+bool read_grid_file(const char *path, GridFile &g, std::string &err);
+
+// Fortran list-directed numeric reader: a READ starts on a new record and continues over following
+// records until its list is satisfied; blanks and commas separate; 'd' exponents accepted.
+class ListReader {
+public:
+  explicit ListReader(const char *path);
+  ~ListReader();
+  bool ok() const { return f_ != nullptr; }
+  // reads n values for one READ statement; returns how many were obtained
+  int64_t read(int64_t n, double *out);
+private:
+  void *f_;
+  std::vector<char> line_;
+};
+
+// es24.15e3 edit descriptor
+void format_es24(double v, char out[25]);
+
+} // namespace srt_host

@@ -1,0 +1,570 @@
+// srt_kernels.hpp -- kernels of the many-ray Haselgrove integrator (templates over the density model).
+//
+// Launch shape: blocks of exactly one wave (64 threads); one ray per lane.  The trace kernel is
+// persistent: each wave pulls rays from a global queue, integrates all its lanes in lock step (one
+// RK attempt per loop trip) and refills lanes whose rays have stopped (wavefront ballot + one atomic
+// per refill) until the queue is empty -- every wave reaches that exit.
+#pragma once
+#include "srt_models.hpp"
+
+namespace srt {
+
+struct TraceParams {
+  double dt0, dtmax, tmax, maxerr, minalt, del;
+  int maxsteps, root, fixedstep, outputper, first_attempt_policy, refill_threshold;
+  int slots;
+};
+
+struct TraceArgs {
+  const double *pos0; // SoA [3][nrays]
+  const double *dir0; // SoA [3][nrays]
+  const double *w0;
+  long long nrays;
+  double *rows;       // [nrays][slots][ROW]
+  int *nrows;         // [nrays]
+  int *stopcond;      // [nrays]
+  unsigned long long *counters; // [0] queue head, [1] accepted steps, [2] attempts
+  TraceParams p;
+};
+
+// raytracer_evalrhs (raytracer.f95:282-314) for the state (x[0..2] position, x[3..5] wave vector).
+// 7 distinct plasma evaluations (centre + 6 stencil points; the reference evaluates the centre twice),
+// 3 + 2 + 6 Stix evaluations, 14 dispersion-function evaluations.
+template <class M>
+__device__ __forceinline__ void evalrhs(const M &m, const Common &cm, const double x[6], double w, double del,
+                                        double rhs[6], double *lds) {
+  double p[7][3];
+  double d[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) d[c] = fd_step(del, x[c]);
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    p[i][0] = x[0];
+    p[i][1] = x[1];
+    p[i][2] = x[2];
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    p[1 + 2 * c][c] = x[c] + d[c];
+    p[2 + 2 * c][c] = x[c] - d[c];
+  }
+  double Ns[7][4];
+  m.template density<7>(p, Ns, lds);
+
+  double B[3];
+  bfield(cm.fld, x[0], x[1], x[2], B);
+  double B2 = B[0] * B[0] + B[1] * B[1] + B[2] * B[2];
+  double Bmag = sqrt(B2);
+  const double *k = x + 3;
+  Stix st0 = stix_parameters(cm.sp, w, Ns[0], Bmag);
+  double cw = cm.C / w;
+  double dk[3];
+  dFdk(st0, k, cw, B, B2, dk);
+  double dw = dFdw(cm.sp, k, w, cm.C, Ns[0], B, B2, Bmag);
+  double n[3] = {k[0] * cw, k[1] * cw, k[2] * cw};
+  double dx[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    double Fpm[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int i = 1 + 2 * c + s;
+      double Bp[3];
+      bfield(cm.fld, p[i][0], p[i][1], p[i][2], Bp);
+      double Bp2 = Bp[0] * Bp[0] + Bp[1] * Bp[1] + Bp[2] * Bp[2];
+      Stix st = stix_parameters(cm.sp, w, Ns[i], sqrt(Bp2));
+      Fpm[s] = dispersion_F(st, n, Bp, Bp2);
+    }
+    dx[c] = (Fpm[0] - Fpm[1]) / d[c] * 0.5;
+  }
+  double idw = 1.0 / dw;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    rhs[c] = -(dk[c] * idw);
+    rhs[3 + c] = dx[c] * idw;
+  }
+}
+
+// Explicit RK stage loop shared by rk4 (raytracer.f95:504-532) and rk45 (:534-596).
+// Stage vectors live in registers with static indices; the stage loop is not unrolled so that a
+// single copy of evalrhs sits in the instruction cache.
+struct Tableau {
+  double a[6][5];
+  int stages;
+};
+__constant__ Tableau TAB_RKF45 = {{{0, 0, 0, 0, 0},
+                                   {rkf::a21, 0, 0, 0, 0},
+                                   {rkf::a31, rkf::a32, 0, 0, 0},
+                                   {rkf::a41, rkf::a42, rkf::a43, 0, 0},
+                                   {rkf::a51, rkf::a52, rkf::a53, rkf::a54, 0},
+                                   {rkf::a61, rkf::a62, rkf::a63, rkf::a64, rkf::a65}},
+                                  6};
+__constant__ Tableau TAB_RK4 = {{{0, 0, 0, 0, 0}, {0.5, 0, 0, 0, 0}, {0, 0.5, 0, 0, 0}, {0, 0, 1.0, 0, 0},
+                                 {0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}},
+                                4};
+
+template <class M>
+__device__ __forceinline__ void rk_stages(const M &m, const Common &cm, const Tableau &tab, const double x[6],
+                                          double w, double del, double dt, double (&ks)[6][6], double *lds) {
+#pragma unroll
+  for (int j = 0; j < 6; ++j)
+#pragma unroll
+    for (int c = 0; c < 6; ++c) ks[j][c] = 0.0;
+#pragma unroll 1
+  for (int s = 0; s < tab.stages; ++s) {
+    double tmp[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      double acc = 0.0;
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        double aj = tab.a[s][j]; // wave-uniform (scalar load)
+        if (j < s) acc += aj * ks[j][c];
+      }
+      tmp[c] = x[c] + acc;
+    }
+    double r[6];
+    evalrhs(m, cm, tmp, w, del, r, lds);
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+      if (j == s) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) ks[j][c] = dt * r[c];
+      }
+  }
+}
+
+__device__ __forceinline__ void rk4_combine(const double x[6], const double (&ks)[6][6], double out[6]) {
+#pragma unroll
+  for (int c = 0; c < 6; ++c)
+    out[c] = x[c] + (1.0 / 6.0) * (ks[0][c] + 2.0 * ks[1][c] + 2.0 * ks[2][c] + ks[3][c]);
+}
+__device__ __forceinline__ void rk45_combine(const double x[6], const double (&ks)[6][6], double o4[6],
+                                             double o5[6]) {
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    o4[c] = x[c] + (rkf::b41 * ks[0][c] + rkf::b43 * ks[2][c] + rkf::b44 * ks[3][c] + rkf::b45 * ks[4][c]);
+    o5[c] = x[c] + (rkf::b51 * ks[0][c] + rkf::b53 * ks[2][c] + rkf::b54 * ks[3][c] + rkf::b55 * ks[4][c] +
+                    rkf::b56 * ks[5][c]);
+  }
+}
+
+// Plasma state at one position plus the derived quantities a trajectory row needs.
+struct PointState {
+  double Ns[4];
+  double B[3], B2, Bmag;
+};
+
+// group velocity pieces at (x, k, w): dfdk, dfdw (raytracer.f95:916-919 / :700-703)
+__device__ __forceinline__ void group_terms(const Common &cm, const PointState &ps, const double k[3], double w,
+                                            double dk[3], double &dw) {
+  Stix st = stix_parameters(cm.sp, w, ps.Ns, ps.Bmag);
+  dFdk(st, k, cm.C / w, ps.B, ps.B2, dk);
+  dw = dFdw(cm.sp, k, w, cm.C, ps.Ns, ps.B, ps.B2, ps.Bmag);
+}
+
+__device__ __forceinline__ void store_row(double *row, double t, const double x[6], const double vp[3],
+                                          const double vg[3], const double n[3], const PointState &ps) {
+  row[0] = t;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    row[1 + c] = x[c];
+    row[4 + c] = vp[c];
+    row[7 + c] = vg[c];
+    row[10 + c] = n[c];
+    row[13 + c] = ps.B[c];
+  }
+#pragma unroll
+  for (int s = 0; s < 4; ++s) row[16 + s] = ps.Ns[s];
+}
+
+// =============================================================================================
+// raytracer_run for a whole launch set (raytracer.f95:609-995 x the driver loop :1144-1232).
+template <class M, bool FIXED, bool USE_LDS>
+__global__ __launch_bounds__(64) void trace_kernel(const M *__restrict__ mp, const Common *__restrict__ cp, TraceArgs a) {
+  const M &m = *mp;
+  const Common &cm = *cp;
+  __shared__ double tile[USE_LDS ? TILE_DOUBLES : 1];
+  double *lds = tile;
+  const TraceParams &P = a.p;
+  const int lane = threadIdx.x;
+  const Tableau &tab = FIXED ? TAB_RK4 : TAB_RKF45;
+
+  // per-lane ray state (registers for the whole life of the ray)
+  long long ray = -1;
+  bool active = false, needinit = false;
+  bool queue_empty = false; // wave-uniform
+  double x[6] = {2.0 * R_E, 0.0, 0.5 * R_E, 1e-3, 0.0, 1e-4}; // benign state for lanes without a ray
+  double w = 2.0e4, t = 0.0, dt = P.dt0, w0 = w;
+  double vg[3] = {0, 0, 0};
+  double dirv[3] = {0, 0, 0};
+  int nstep = 1, lastrefinedown = 0;
+  bool first_attempt = true;
+  unsigned long long acc_steps = 0, acc_attempts = 0;
+  const int threshold = P.refill_threshold > 0 ? P.refill_threshold : 4;
+
+  for (;;) {
+    // ---- A. loop-top tests of raytracer_run (:749-763)
+    if (active) {
+      int stop = -1;
+      if (t >= P.tmax) stop = 0;
+      else {
+        int sc = stop_conditions(x, vg, dt, nstep, P.maxsteps, P.minalt);
+        if (sc != 0) stop = sc;
+      }
+      if (stop >= 0) {
+        a.nrows[ray] = nstep;
+        a.stopcond[ray] = stop;
+        acc_steps += (unsigned long long)(nstep - 1);
+        active = false;
+      }
+    }
+    // ---- B. refill free lanes from the queue (ballot compaction)
+    unsigned long long freemask = __ballot(!active);
+    int nfree = __popcll(freemask);
+    if (!queue_empty && (nfree >= threshold || nfree == WAVE)) {
+      unsigned long long base = 0;
+      if (lane == 0) base = atomicAdd(a.counters, (unsigned long long)nfree);
+      base = __shfl(base, 0);
+      if (!active) {
+        int rank = __popcll(freemask & ((1ull << lane) - 1ull));
+        long long id = (long long)base + rank;
+        if (id < a.nrays) {
+          ray = id;
+          needinit = true;
+          x[0] = a.pos0[id];
+          x[1] = a.pos0[a.nrays + id];
+          x[2] = a.pos0[2 * a.nrays + id];
+          dirv[0] = a.dir0[id];
+          dirv[1] = a.dir0[a.nrays + id];
+          dirv[2] = a.dir0[2 * a.nrays + id];
+          w0 = a.w0[id];
+        }
+      }
+      if ((long long)base + nfree >= a.nrays) queue_empty = true;
+    }
+    // ---- C. initialise newly claimed rays (:661-742); whole wave takes the branch together
+    if (__any(needinit)) {
+      double p1[1][3] = {{x[0], x[1], x[2]}};
+      double N1[1][4];
+      m.template density<1>(p1, N1, lds);
+      PointState ps;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) ps.Ns[s] = N1[0][s];
+      bfield(cm.fld, x[0], x[1], x[2], ps.B);
+      ps.B2 = ps.B[0] * ps.B[0] + ps.B[1] * ps.B[1] + ps.B[2] * ps.B[2];
+      ps.Bmag = sqrt(ps.B2);
+      if (needinit) {
+        double dir[3] = {dirv[0], dirv[1], dirv[2]};
+        if (dir[0] == 0.0 && dir[1] == 0.0 && dir[2] == 0.0) {
+          // field-aligned start: B/|B| with the radial component made positive (:661-674)
+          double rr = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+          double er[3] = {x[0] / rr, x[1] / rr, x[2] / rr};
+          double br = ps.B[0] * er[0] + ps.B[1] * er[1] + ps.B[2] * er[2];
+          double adj = fabs(br) - br; // flip the radial part when negative
+#pragma unroll
+          for (int c = 0; c < 3; ++c) dir[c] = ps.B[c] + adj * er[c];
+          double nb = sqrt(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) dir[c] /= nb;
+        }
+        Roots rt = solve_dispersion(cm, dir, w0, ps.Ns, ps.B);
+        double kre = (P.root == 1) ? rt.k1re : rt.k2re;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) x[3 + c] = kre * dir[c]; // real(k0mag*dir0)
+        w = w0;
+        t = 0.0;
+        dt = P.dt0;
+        lastrefinedown = 0;
+        nstep = 1;
+        first_attempt = true;
+        // row 0 (:700-742)
+        double dk[3], dw;
+        group_terms(cm, ps, x + 3, w, dk, dw);
+        double cw = cm.C / w;
+        double n[3] = {x[3] * cw, x[4] * cw, x[5] * cw};
+        double nn = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
+        double vp[3];
+        if (nn > 0.0) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            vp[c] = n[c] / nn;
+            vg[c] = -(dk[c] / dw) / cm.C;
+          }
+        } else {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) vp[c] = vg[c] = 0.0;
+        }
+        store_row(a.rows + (size_t)ray * (size_t)P.slots * ROW, t, x, vp, vg, n, ps);
+        active = true;
+        needinit = false;
+      }
+      continue; // new rays go through the loop-top tests before their first attempt
+    }
+    // ---- D. exit when nothing is left (every wave reaches this)
+    if (nfree == WAVE) {
+      if (queue_empty) break;
+      continue;
+    }
+
+    // ---- E. one attempt for every lane (:770-817)
+    acc_attempts += active ? 1ull : 0ull;
+    double ks[6][6];
+    rk_stages(m, cm, tab, x, w, P.del, dt, ks, lds);
+    double est1[6], est2[6];
+    bool reject = false;
+    const double dtincr = dt;
+    if (FIXED) {
+      rk4_combine(x, ks, est2);
+#pragma unroll
+      for (int c = 0; c < 6; ++c) est1[c] = est2[c];
+    } else {
+      rk45_combine(x, ks, est1, est2);
+    }
+    // plasma state at est1 and est2 positions: one tile staging serves both; the est2 state also
+    // serves the root re-projection and the output row (the reference evaluates it 4 times)
+    double p2[2][3] = {{est2[0], est2[1], est2[2]}, {est1[0], est1[1], est1[2]}};
+    double N2[2][4];
+    m.template density<2>(p2, N2, lds);
+    PointState ps2;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) ps2.Ns[s] = N2[0][s];
+    bfield(cm.fld, est2[0], est2[1], est2[2], ps2.B);
+    ps2.B2 = ps2.B[0] * ps2.B[0] + ps2.B[1] * ps2.B[1] + ps2.B[2] * ps2.B[2];
+    ps2.Bmag = sqrt(ps2.B2);
+    if (!FIXED) {
+      // error term (:778-788): max of the relative differences in k and in dF/dk
+      double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+      for (int c = 3; c < 6; ++c) {
+        s1 += fabs(est1[c] - est2[c]);
+        s2 += fabs(est2[c]);
+      }
+      double kterm = s1 / s2;
+      double err;
+      if (first_attempt) {
+        // the reference reads its local w before assigning it (SURVEY A-1)
+        err = (P.first_attempt_policy == 1) ? kterm : __builtin_nan("");
+      } else {
+        PointState ps1;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) ps1.Ns[s] = N2[1][s];
+        bfield(cm.fld, est1[0], est1[1], est1[2], ps1.B);
+        ps1.B2 = ps1.B[0] * ps1.B[0] + ps1.B[1] * ps1.B[1] + ps1.B[2] * ps1.B[2];
+        ps1.Bmag = sqrt(ps1.B2);
+        double d1[3], d2[3];
+        Stix st1 = stix_parameters(cm.sp, w, ps1.Ns, ps1.Bmag);
+        dFdk(st1, est1 + 3, cm.C / w, ps1.B, ps1.B2, d1);
+        Stix st2 = stix_parameters(cm.sp, w, ps2.Ns, ps2.Bmag);
+        dFdk(st2, est2 + 3, cm.C / w, ps2.B, ps2.B2, d2);
+        double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          t1 += fabs(d1[c] - d2[c]);
+          t2 += fabs(d2[c]);
+        }
+        double dterm = t1 / t2;
+        err = (kterm > dterm) ? kterm : dterm; // flang's MAX(x,y)
+      }
+      if (err > P.maxerr) {
+        reject = true;
+        if (active) {
+          dt = 0.8 * dt;
+          lastrefinedown = 1;
+        }
+      } else if (active && lastrefinedown == 0 && err < P.maxerr / 100.0 && dt * 1.25 < P.dtmax) {
+        dt = dt * 1.25;
+      }
+    }
+    // ---- F. re-project |k| on the chosen root, keep direction (:819-836)
+    Roots rt = solve_dispersion(cm, est2 + 3, w, ps2.Ns, ps2.B);
+    double kmre = (P.root == 1) ? rt.k1re : rt.k2re;
+    double kmim = (P.root == 1) ? rt.k1im : rt.k2im;
+    double kn = sqrt(est2[3] * est2[3] + est2[4] * est2[4] + est2[5] * est2[5]);
+    double knew[3], imsum = 0.0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      double u = est2[3 + c] / kn;
+      knew[c] = kmre * u;
+      double im = kmim * u;
+      imsum += im * im;
+    }
+    if (active && !reject) {
+      first_attempt = false; // w = est2(7) is assigned from here on (:821)
+      if (imsum > 0.0) {
+        // outside the resonance cone (:891-906)
+        if (!FIXED) {
+          dt = dt / 2.0;
+          lastrefinedown = 1;
+        } else {
+          a.nrows[ray] = nstep; // `return` with stopcond 0 and a truncated trajectory
+          a.stopcond[ray] = 0;
+          acc_steps += (unsigned long long)(nstep - 1);
+          active = false;
+        }
+      } else {
+        // ---- G. accept (:908-986)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          x[c] = est2[c];
+          x[3 + c] = knew[c];
+        }
+        lastrefinedown = 0;
+        t = t + dtincr;
+        nstep = nstep + 1;
+        double dk[3], dw;
+        group_terms(cm, ps2, x + 3, w, dk, dw);
+        double cw = cm.C / w;
+        double n[3] = {x[3] * cw, x[4] * cw, x[5] * cw};
+        double nn = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
+        double vp[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          vp[c] = n[c] / nn;
+          vg[c] = -(dk[c] / dw) / cm.C;
+        }
+        const int row = nstep - 1;
+        if (row % P.outputper == 0) {
+          int slot = row / P.outputper;
+          if (slot < P.slots)
+            store_row(a.rows + ((size_t)ray * (size_t)P.slots + (size_t)slot) * ROW, t, x, vp, vg, n, ps2);
+        }
+      }
+    }
+  }
+  // per-wave totals
+  for (int off = 32; off > 0; off >>= 1) {
+    acc_steps += __shfl_down(acc_steps, off);
+    acc_attempts += __shfl_down(acc_attempts, off);
+  }
+  if (lane == 0) {
+    atomicAdd(a.counters + 1, acc_steps);
+    atomicAdd(a.counters + 2, acc_attempts);
+  }
+}
+
+// =============================================================================================
+// Layered kernels for the parity ladder (one item per lane; all lanes of a wave participate).
+
+// funcPlasmaParams: out[n][19] = qs(4) Ns(4) ms(4) nus(4) B0(3)
+template <class M, bool USE_LDS>
+__global__ __launch_bounds__(64) void params_kernel(const M *__restrict__ mp, const Common *__restrict__ cp, long long n, const double *x, double *out) {
+  const M &m = *mp;
+  const Common &cm = *cp;
+  __shared__ double tile[USE_LDS ? TILE_DOUBLES : 1];
+  long long i = (long long)blockIdx.x * WAVE + threadIdx.x;
+  long long j = i < n ? i : n - 1;
+  double p[1][3] = {{x[3 * j], x[3 * j + 1], x[3 * j + 2]}};
+  double Ns[1][4];
+  m.template density<1>(p, Ns, tile);
+  double B[3];
+  bfield(cm.fld, p[0][0], p[0][1], p[0][2], B);
+  if (i < n) {
+    double *o = out + 19 * i;
+    for (int s = 0; s < 4; ++s) {
+      o[s] = cm.sp.q[s];
+      o[4 + s] = Ns[0][s];
+      o[8 + s] = cm.sp.m[s];
+      o[12 + s] = 0.0;
+    }
+    for (int c = 0; c < 3; ++c) o[16 + c] = B[c];
+  }
+}
+
+// out[n][10] = F, S, D, P, R, L, Re k1, Im k1, Re k2, Im k2
+template <class M, bool USE_LDS>
+__global__ __launch_bounds__(64) void dispersion_kernel(const M *__restrict__ mp, const Common *__restrict__ cp, long long n, const double *x,
+                                                        const double *k, const double *w, double *out) {
+  const M &m = *mp;
+  const Common &cm = *cp;
+  __shared__ double tile[USE_LDS ? TILE_DOUBLES : 1];
+  long long i = (long long)blockIdx.x * WAVE + threadIdx.x;
+  long long j = i < n ? i : n - 1;
+  double p[1][3] = {{x[3 * j], x[3 * j + 1], x[3 * j + 2]}};
+  double kk[3] = {k[3 * j], k[3 * j + 1], k[3 * j + 2]};
+  double ww = w[j];
+  double Ns[1][4];
+  m.template density<1>(p, Ns, tile);
+  double B[3];
+  bfield(cm.fld, p[0][0], p[0][1], p[0][2], B);
+  double B2 = B[0] * B[0] + B[1] * B[1] + B[2] * B[2];
+  Stix st = stix_parameters(cm.sp, ww, Ns[0], sqrt(B2));
+  double cw = cm.C / ww;
+  double nv[3] = {kk[0] * cw, kk[1] * cw, kk[2] * cw};
+  double F = dispersion_F(st, nv, B, B2);
+  Roots rt = solve_dispersion(cm, kk, ww, Ns[0], B);
+  if (i < n) {
+    double *o = out + 10 * i;
+    o[0] = F; o[1] = st.S; o[2] = st.D; o[3] = st.P; o[4] = st.R; o[5] = st.L;
+    o[6] = rt.k1re; o[7] = rt.k1im; o[8] = rt.k2re; o[9] = rt.k2im;
+  }
+}
+
+// out[n][14] = dFdk(3), dFdw, dFdx(3), rhs(7)
+template <class M, bool USE_LDS>
+__global__ __launch_bounds__(64) void gradients_kernel(const M *__restrict__ mp, const Common *__restrict__ cp, long long n, const double *x,
+                                                       const double *k, const double *w, double del,
+                                                       double *out) {
+  const M &m = *mp;
+  const Common &cm = *cp;
+  __shared__ double tile[USE_LDS ? TILE_DOUBLES : 1];
+  long long i = (long long)blockIdx.x * WAVE + threadIdx.x;
+  long long j = i < n ? i : n - 1;
+  double st[6] = {x[3 * j], x[3 * j + 1], x[3 * j + 2], k[3 * j], k[3 * j + 1], k[3 * j + 2]};
+  double ww = w[j];
+  double rhs[6];
+  evalrhs(m, cm, st, ww, del, rhs, tile);
+  // recover the gradients themselves: dfdw from a second (cheap) evaluation at the centre
+  double p[1][3] = {{st[0], st[1], st[2]}};
+  double Ns[1][4];
+  m.template density<1>(p, Ns, tile);
+  PointState ps;
+  for (int s = 0; s < 4; ++s) ps.Ns[s] = Ns[0][s];
+  bfield(cm.fld, st[0], st[1], st[2], ps.B);
+  ps.B2 = ps.B[0] * ps.B[0] + ps.B[1] * ps.B[1] + ps.B[2] * ps.B[2];
+  ps.Bmag = sqrt(ps.B2);
+  double dk[3], dw;
+  group_terms(cm, ps, st + 3, ww, dk, dw);
+  if (i < n) {
+    double *o = out + 14 * i;
+    for (int c = 0; c < 3; ++c) {
+      o[c] = dk[c];
+      o[4 + c] = rhs[3 + c] * dw; // dfdx = rhs*dfdw
+      o[7 + c] = rhs[c];
+      o[10 + c] = rhs[3 + c];
+    }
+    o[3] = dw;
+    o[13] = 0.0;
+  }
+}
+
+// out[n][21] = rk4(7), rk45 4th(7), rk45 5th(7)
+template <class M, bool USE_LDS>
+__global__ __launch_bounds__(64) void rkstep_kernel(const M *__restrict__ mp, const Common *__restrict__ cp, long long n, const double *args,
+                                                    const double *dtv, double del, double *out) {
+  const M &m = *mp;
+  const Common &cm = *cp;
+  __shared__ double tile[USE_LDS ? TILE_DOUBLES : 1];
+  long long i = (long long)blockIdx.x * WAVE + threadIdx.x;
+  long long j = i < n ? i : n - 1;
+  double st[6];
+  for (int c = 0; c < 6; ++c) st[c] = args[7 * j + c];
+  double ww = args[7 * j + 6], dt = dtv[j];
+  double ks[6][6];
+  double r4[6], o4[6], o5[6];
+  rk_stages(m, cm, TAB_RK4, st, ww, del, dt, ks, tile);
+  rk4_combine(st, ks, r4);
+  rk_stages(m, cm, TAB_RKF45, st, ww, del, dt, ks, tile);
+  rk45_combine(st, ks, o4, o5);
+  if (i < n) {
+    double *o = out + 21 * i;
+    for (int c = 0; c < 6; ++c) {
+      o[c] = r4[c];
+      o[7 + c] = o4[c];
+      o[14 + c] = o5[c];
+    }
+    o[6] = o[13] = o[20] = ww;
+  }
+}
+
+} // namespace srt

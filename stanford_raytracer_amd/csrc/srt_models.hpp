@@ -1,0 +1,293 @@
+// srt_models.hpp -- device-side density models (the reference's funcPlasmaParams adapters).
+//
+// Every model exposes
+//     template <int NP> __device__ void density(const double (&p)[NP][3], double (&Ns)[NP][4], double *lds)
+// which must be called by ALL 64 lanes of the wave together (the interp model stages coefficient
+// tiles through LDS cooperatively).  Blocks are exactly one wave (64 threads).
+#pragma once
+#include "srt_device.hpp"
+
+namespace srt {
+
+constexpr int WAVE = 64;
+constexpr int TILE_STRIDE = 65;                 // doubles per lane row in LDS (64 + 1 pad: conflict-free b64 reads)
+constexpr int TILE_DOUBLES = WAVE * TILE_STRIDE; // 33,280 B per wave
+
+// =============================================================================================
+// modelnum = 1: Ngo diffusive-equilibrium model.
+// ngo_dens_model_adapter.f95:105-140 (adapter head) + ngo_dens_model.f95:165-353 (dens).
+// Trig-free restatement: with phi the colatitude the adapter computes L = r/(R_E sin^2 phi),
+// lam = 90 - phi (deg) and z(1) = r0*L*cos^2(lam) = r0*r/R_E, z(2) = phi; dens() needs only z(1),
+// sin^2 z(2) = rho^2/r^2 and the sign of the latitude.
+struct NgoModel {
+  // state read by dens(): see ngo_dens_model.f95:8-24 and readinput :29-160
+  double r0, pi32;
+  double therm, rbase, ane0, alpha0[5], rzero, scbot;
+  double lk, expk, ddk, rconsn, scr;
+  double l0[10], def[10], dd[10], rducln[10], rducun[10], rducls[10], rducus[10], sidedu[10];
+  double hl2n[10], hl2s[10], hu2n[10], hu2s[10];
+  int num, kducts, kinit;
+
+  __device__ inline void dens_point(double x, double y, double z, double Ns[4]) const {
+    double rho2 = x * x + y * y;
+    double r2 = rho2 + z * z;
+    double r = sqrt(r2);
+    // z(1) = r0*L*cos^2(lam) = r0*r/R_E ; sin^2 z(2) = rho^2/r^2 ; only the sign of the latitude is used
+    dens_core(r0 * r / R_E, rho2 / r2, z, Ns);
+  }
+
+  // dens (ngo_dens_model.f95:165-353) entered with z(1), sin^2 z(2) and the latitude
+  __device__ inline void dens_core(double z1, double sinz22, double latitu, double Ns[4]) const {
+    // scale heights (:180-186); 1.150600 is a default-real literal (SURVEY A-6)
+    double rb7370 = rbase / 7370.0;
+    double sh2 = (double)1.150600f * therm * rb7370 * rb7370;
+    double gph = rbase * (1.0 - rbase / z1);
+    double e2 = exp(-gph / sh2);
+    double e3 = e2 * e2 * e2 * e2;
+    double e4 = e3 * e3 * e3 * e3;
+    double q2 = alpha0[2] * e2, q3 = (num >= 3) ? alpha0[3] * e3 : 0.0, q4 = (num >= 4) ? alpha0[4] * e4 : 0.0;
+    double q = q2 + q3 + q4;
+    double anr = sqrt(q);
+    double arg = (z1 - rzero) / scbot;
+    if (!(arg < 13.0)) arg = 13.0;
+    double anli = 1.0 - exp(-arg * arg);
+    double l = z1 / (r0 * sinz22);
+    double ani1 = ane0 * anr * anli;
+    if (kducts != 0) {
+      double deltal = l - lk;
+      if (!(deltal < 0.0)) { // plasmapause (:218-239)
+        double d2 = ddk * ddk;
+        double argl = deltal * deltal / (d2 * 2.0);
+        if (!(argl < 80.0)) argl = 80.0;
+        double f = exp(-argl);
+        double trm = pow(rconsn / z1, expk);
+        double argr = (z1 - rconsn) / scr;
+        if (!(argr < 12.5)) argr = 12.5;
+        double fr = exp(-argr * argr);
+        double trmodl = trm + (1.0 - trm) * fr;
+        ani1 *= f + trmodl * (1.0 - f);
+      }
+      if (kducts != 1) ani1 *= ducts(l, z1, latitu);
+    }
+    double invq = 1.0 / q;
+    Ns[0] = 1.0e6 * ani1;
+    Ns[1] = 1.0e6 * (ani1 * (q2 * invq));
+    Ns[2] = 1.0e6 * (ani1 * (q3 * invq));
+    Ns[3] = 1.0e6 * (ani1 * (q4 * invq));
+  }
+
+  // altitude taper shared by the sinusoidal perturbation and the ducts (:250-276, :299-327).
+  // Returns false when the contribution is skipped entirely (arglr >= 75).
+  __device__ inline bool taper(int kd, double z1, double latitu, bool north_first, double &delnl) const {
+    bool lower;
+    if (north_first)
+      lower = (latitu >= 0 && z1 <= rducun[kd]) || (latitu <= 0 && z1 <= rducus[kd]);
+    else
+      lower = (latitu <= 0 && z1 <= rducus[kd]) || (latitu >= 0 && z1 <= rducun[kd]);
+    double delr = 0.0, arglr = 0.0;
+    if (!lower) { // above the upper edge
+      if (north_first) {
+        if (latitu >= 0) delr = z1 - rducun[kd];
+        if (latitu <= 0) delr = z1 - rducus[kd];
+        if (latitu >= 0) arglr = delr * delr / hu2n[kd];
+        if (latitu <= 0) arglr = delr * delr / hu2s[kd];
+      } else {
+        if (latitu >= 0) delr = z1 - rducun[kd];
+        if (latitu <= 0) delr = z1 - rducus[kd];
+        if (latitu <= 0) arglr = delr * delr / hu2s[kd];
+        if (latitu >= 0) arglr = delr * delr / hu2n[kd];
+      }
+      if (arglr >= 75.0) return false;
+      delnl *= exp(-arglr);
+      return true;
+    }
+    bool inside;
+    if (north_first)
+      inside = (latitu >= 0 && z1 >= rducln[kd]) || (latitu <= 0 && z1 >= rducls[kd]);
+    else
+      inside = (latitu <= 0 && z1 >= rducls[kd]) || (latitu >= 0 && z1 >= rducln[kd]);
+    if (inside) return true;
+    if (latitu >= 0) delr = z1 - rducln[kd];
+    if (latitu <= 0) delr = z1 - rducls[kd];
+    if (north_first) {
+      if (latitu >= 0) arglr = delr * delr / hl2n[kd];
+      if (latitu <= 0) arglr = delr * delr / hl2s[kd];
+    } else {
+      if (latitu <= 0) arglr = delr * delr / hl2s[kd];
+      if (latitu >= 0) arglr = delr * delr / hl2n[kd];
+    }
+    if (arglr >= 75.0) return false;
+    delnl *= exp(-arglr);
+    return true;
+  }
+
+  __device__ __noinline__ double ducts(double l, double z1, double latitu) const {
+    double fac = 1.0;
+    int kstart = kinit;
+    if (!(l0[2] > 0.0)) { // sinusoidal density perturbation (:241-288)
+      kstart = 3;
+      double dl = l + l0[2];
+      if (!(dl * sidedu[2] >= 0.0)) dl = 0.0;
+      double delk = -l0[2] - (lk + ddk) + dd[2] / 2;
+      double critl = (lk + ddk) + fmod(delk, dd[2]);
+      if (!(l <= critl)) {
+        double argl = 2.0 * pi32 * dl / dd[2];
+        double delnl = (def[2] / 2.0) * (1.0 + cos(argl));
+        if (taper(2, z1, latitu, false, delnl)) fac *= 1.0 + delnl;
+      }
+      if (kducts == 2) return fac;
+    }
+    for (int kd = kstart; kd <= kducts; ++kd) { // gaussian ducts (:289-336)
+      double dl = l - l0[kd];
+      if (!(dl * sidedu[kd] >= 0.0)) dl = 0.0;
+      double d2 = dd[kd] * dd[kd];
+      double argl = dl * dl / (d2 * 2.0);
+      if (argl > 80.0) continue;
+      double delnl = def[kd] * exp(-argl);
+      if (taper(kd, z1, latitu, true, delnl)) fac *= 1.0 + delnl;
+    }
+    return fac;
+  }
+
+  template <int NP>
+  __device__ __forceinline__ void density(const double (&p)[NP][3], double (&Ns)[NP][4], double *) const {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) dens_point(p[i][0], p[i][1], p[i][2], Ns[i]);
+  }
+};
+
+// =============================================================================================
+// modelnum = 3: tricubic interpolation of ln N_s on a regular grid
+// (interp_dens_model_adapter.f95:148-210 + libtricubic.f95:796-933).
+//
+// HBM layout: the 64 Lekien-Marsden polynomial coefficients of every cell are expanded ONCE at model
+// creation (srt_build_coeffs kernel = tricubic_get_coeff applied to all cells, including the clamped
+// out-of-range cells and their sticky-flag quirk, SURVEY A-7) into
+//     coef[cell][species][64]  doubles, cell = (ck*(ny+1)+cj)*(nx+1)+ci, ci = #nodes <= x (0..nx)
+// i.e. one contiguous 512 B block per (cell, species), 2 KiB per cell at nspec = 4 -- exactly the
+// 2048 B per lookup that the reference gathers from 8 arrays x 8 corners.  A lookup then is one
+// contiguous block read plus a polynomial evaluation.  Per wave the blocks of all 64 lanes are staged
+// species by species through a 33 KB LDS tile with fully coalesced 512 B reads, and every lane
+// evaluates all its stencil points from the tile.
+struct Axis {
+  double min, del;
+  int n;
+  // node i (0-based): real(i)*del + min, separately rounded like interp_dens_model_adapter.f95:93-95
+  __device__ __forceinline__ double node(int i) const { return __dadd_rn(__dmul_rn((double)i, del), min); }
+  // maxloc(.., mask = 0 <= (xi - x)) (libtricubic.f95:835-840): number of nodes <= xi, and the local
+  // coordinate (:842-856)
+  __device__ __forceinline__ int locate(double xi, double &xl) const {
+    double f = (xi - min) / del;
+    int g;
+    if (!(f >= 0.0)) g = 0;
+    else if (f >= (double)n) g = n;
+    else g = (int)f + 1;
+    while (g < n && node(g) <= xi) ++g;
+    while (g > 0 && node(g - 1) > xi) --g;
+    xl = (g >= 1 && g < n) ? (xi - node(g - 1)) / del : 0.0;
+    return g;
+  }
+};
+
+struct InterpModel {
+  const double *coef; // [ncell][nspec][64]
+  Axis ax, ay, az;
+  int nspec;
+
+  __device__ __forceinline__ int cell_id(int ci, int cj, int ck) const {
+    return (ck * (ay.n + 1) + cj) * (ax.n + 1) + ci;
+  }
+
+  // tricubic_eval with derx=dery=derz=0 (libtricubic.f95:658-695) for NP points that share one cell:
+  // nested Horner, coefficient-outer / point-inner so each coefficient is read once.
+  template <int NP, class Load>
+  __device__ __forceinline__ static void eval(Load a, const double (&x)[NP], const double (&y)[NP],
+                                              const double (&z)[NP], double (&out)[NP]) {
+    double vz[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) vz[i] = 0.0;
+#pragma unroll
+    for (int k = 3; k >= 0; --k) {
+      double vy[NP];
+#pragma unroll
+      for (int i = 0; i < NP; ++i) vy[i] = 0.0;
+#pragma unroll
+      for (int j = 3; j >= 0; --j) {
+        int b = 4 * j + 16 * k;
+        double a0 = a(b), a1 = a(b + 1), a2 = a(b + 2), a3 = a(b + 3);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+          double vx = fma(fma(fma(a3, x[i], a2), x[i], a1), x[i], a0);
+          vy[i] = fma(vy[i], y[i], vx);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NP; ++i) vz[i] = fma(vz[i], z[i], vy[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < NP; ++i) out[i] = vz[i];
+  }
+
+  // rare path: one point, straight from global memory (lane-divergent)
+  __device__ __noinline__ void point_direct(double x, double y, double z, double lnN[4]) const {
+    double xl, yl, zl;
+    int ci = ax.locate(x, xl), cj = ay.locate(y, yl), ck = az.locate(z, zl);
+    const double *base = coef + (size_t)cell_id(ci, cj, ck) * (size_t)(nspec * 64);
+    for (int s = 0; s < nspec; ++s) {
+      const double *a = base + s * 64;
+      double x1[1] = {xl}, y1[1] = {yl}, z1[1] = {zl}, o1[1];
+      eval<1>([&](int i) { return a[i]; }, x1, y1, z1, o1);
+      lnN[s] = o1[0];
+    }
+  }
+
+  template <int NP>
+  __device__ __forceinline__ void density(const double (&p)[NP][3], double (&Ns)[NP][4], double *lds) const {
+    const int lane = threadIdx.x;
+    // cell of point 0; the other points normally share it (FD offsets are ~1e-6 |x| << cell size)
+    double xl[NP], yl[NP], zl[NP];
+    int ci = ax.locate(p[0][0], xl[0]);
+    int cj = ay.locate(p[0][1], yl[0]);
+    int ck = az.locate(p[0][2], zl[0]);
+    unsigned strag = 0; // bit i: point i lies in another cell
+#pragma unroll
+    for (int i = 1; i < NP; ++i) {
+      int c1 = ax.locate(p[i][0], xl[i]);
+      int c2 = ay.locate(p[i][1], yl[i]);
+      int c3 = az.locate(p[i][2], zl[i]);
+      if (c1 != ci || c2 != cj || c3 != ck) strag |= 1u << i;
+    }
+    const int cell = cell_id(ci, cj, ck);
+    double acc[NP][4];
+    for (int s = 0; s < nspec; ++s) {
+      __syncthreads(); // previous readers of the tile are done (block == one wave)
+#pragma unroll 8
+      for (int j = 0; j < WAVE; ++j) {
+        int cj_ = __builtin_amdgcn_readlane(cell, j); // wave-uniform -> scalar address
+        const double *src = coef + ((size_t)cj_ * (size_t)nspec + (size_t)s) * 64;
+        lds[j * TILE_STRIDE + lane] = src[lane]; // 512 B contiguous per instruction
+      }
+      __syncthreads();
+      const double *mine = lds + lane * TILE_STRIDE;
+      double o[NP];
+      eval<NP>([&](int c) { return mine[c]; }, xl, yl, zl, o);
+#pragma unroll
+      for (int i = 0; i < NP; ++i) acc[i][s] = o[i];
+    }
+    if (__any(strag != 0)) {
+#pragma unroll
+      for (int i = 1; i < NP; ++i)
+        if (strag & (1u << i)) {
+          double t[4];
+          point_direct(p[i][0], p[i][1], p[i][2], t);
+          for (int s = 0; s < nspec; ++s) acc[i][s] = t[s];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NP; ++i)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) Ns[i][s] = (s < nspec) ? exp(acc[i][s]) : 0.0; // Ns = exp(Ns) (:206)
+  }
+};
+
+} // namespace srt
