@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native many-ray Haselgrove integrator.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` (N>1: launched by torch.distributed.run,
+one rank per GPU).  A "step" is one pass of the hot path over one batch of synthetic input: the whole
+launch set is traced from t=0 to its stop conditions by one kernel launch.  W untimed steps, then
+exactly K timed steps bracketed by barrier + synchronize; MAX over ranks; rank 0 prints ONE JSON line.
+
+Workloads (BASELINE.json configs; --workload):
+  interp256 (default)  config[2]: 1M rays, interp model on a 256^3 x 4-species ln N grid (tricubic),
+                       adaptive RK45, maxsteps=256, outputper=16 -- the configuration the north-star
+                       metric (ray-steps/s + HBM roofline) is quoted on.
+  ngo100k              config[1]: 100k rays, Ngo model, adaptive RK45, maxsteps=512, outputper=8.
+  Smaller variants for quick checks: --grid N --rays N.
+Inputs are synthetic (seeded launch set + analytic plasmasphere) and resident in HBM
+before the timed region starts.  N>1 is weak scaling: every rank traces its own launch set of the
+same size against its own model replica, then the trajectory buffers are gathered to rank 0 (RCCL).
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGO_BYTES_PER_STEP = {  # algorithmic bytes per ACCEPTED ray-step
+    # 44 distinct lookups x (8 corners x 8 arrays x 4 species x 8 B) + state r/w 160 B + row 256 B/outputper
+    "interp": lambda outputper: 44 * 2048 + 160 + 256.0 / outputper,
+    # no table: state r/w + emitted row only
+    "ngo": lambda outputper: 160 + 256.0 / outputper,
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="interp256", choices=["interp256", "ngo100k"])
+    ap.add_argument("--rays", type=int, default=0, help="override rays per GPU")
+    ap.add_argument("--grid", type=int, default=0, help="override grid nodes per axis (interp)")
+    ap.add_argument("--maxsteps", type=int, default=0)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline sample duration (0=skip)")
+    ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--refill", type=int, default=0)
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+
+        dist = dist_
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+
+    from stanford_raytracer_amd import api, workloads as wl
+
+    api.init(local_rank)
+
+    # ---------------------------------------------------------------- workload
+    if args.workload == "interp256":
+        kind = "interp"
+        nrays = args.rays or 1_000_000
+        grid_n = args.grid or 256
+        seed = 3
+        p = api.make_params(fixedstep=0, dt0=1e-3, dtmax=0.1, maxerr=5e-4, tmax=0.5, root=2, minalt=wl.MINALT,
+                            maxsteps=args.maxsteps or 256, outputper=16, del_=1e-6, refill_threshold=args.refill)
+        t0 = time.time()
+        F, bounds = wl.make_grid(grid_n, half_width=10.0 * wl.R_E)
+        model = api.Model.interp(F, bounds, wl.QS, wl.MS)
+        del F
+        setup_s = time.time() - t0
+        wname = "%d rays/GPU, interp_dens_model on %d^3 x4 lnN grid (tricubic), dipole B, adaptive RK45" % (nrays, grid_n)
+    else:
+        kind = "ngo"
+        nrays = args.rays or 100_000
+        grid_n = 0
+        seed = 2
+        p = api.make_params(fixedstep=0, dt0=1e-3, dtmax=0.1, maxerr=5e-4, tmax=0.5, root=2, minalt=wl.MINALT,
+                            maxsteps=args.maxsteps or 512, outputper=8, del_=1e-4, refill_threshold=args.refill)
+        t0 = time.time()
+        cfg = os.path.join(tempfile.mkdtemp(), "newray.in")
+        with open(cfg, "w") as f:
+            f.write(wl.NEWRAY_PLASMAPAUSE)
+        model = api.Model.ngo(cfg)
+        setup_s = time.time() - t0
+        wname = "%d rays/GPU, ngo_dens_model, dipole B, adaptive RK45" % nrays
+
+    pos0, dir0, w0 = wl.launch_set(nrays, seed + 1000 * rank)
+    slots = api.lib().srt_rows_per_ray(p)
+    d_pos = torch.from_numpy(np.ascontiguousarray(pos0.T)).to(dev)  # SoA [3][n]
+    d_dir = torch.from_numpy(np.ascontiguousarray(dir0.T)).to(dev)
+    d_w = torch.from_numpy(w0).to(dev)
+    d_rows = torch.zeros((nrays, slots, api.ROW), dtype=torch.float64, device=dev)
+    d_nrows = torch.zeros(nrays, dtype=torch.int32, device=dev)
+    d_stop = torch.zeros(nrays, dtype=torch.int32, device=dev)
+    d_cnt = torch.zeros(4, dtype=torch.int64, device=dev)
+    gather_buf = None
+    if dist is not None and not args.no_gather and rank == 0:
+        gather_buf = [torch.empty_like(d_rows) for _ in range(world)]
+
+    import ctypes as C
+
+    stream = torch.cuda.current_stream(dev)
+
+    def one_step():
+        rc = api.lib().srt_trace_batch_device(model.h, C.byref(p), nrays, d_pos.data_ptr(), d_dir.data_ptr(),
+                                              d_w.data_ptr(), d_rows.data_ptr(), d_nrows.data_ptr(),
+                                              d_stop.data_ptr(), d_cnt.data_ptr(), stream.cuda_stream)
+        if rc != 0:
+            raise RuntimeError(api.lib().srt_last_error().decode())
+        if dist is not None and not args.no_gather:
+            dist.gather(d_rows, gather_buf, dst=0)
+
+    def sync_all():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        one_step()
+    sync_all()
+    kernel_ms = []
+    steps_acc = 0
+    attempts = 0
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+        # per-launch kernel duration from HIP events recorded on the launch stream inside the library
+        kernel_ms.append(model.last_kernel_ms())
+        c = d_cnt.cpu().numpy()
+        steps_acc += int(c[1])
+        attempts += int(c[2])
+    sync_all()
+    elapsed = time.perf_counter() - t_start
+
+    tot_steps, tmax = steps_acc, elapsed
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        s = torch.tensor([steps_acc], dtype=torch.int64, device=dev)
+        dist.all_reduce(s, op=dist.ReduceOp.SUM)
+        tmax, tot_steps = float(t.item()), int(s.item())
+
+    if rank == 0:
+        stop = d_stop.cpu().numpy()
+        nrows = d_nrows.cpu().numpy()
+        steps_per_launch = steps_acc / max(args.steps, 1)
+        k_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
+        algo = ALGO_BYTES_PER_STEP[kind](p.outputper) * steps_per_launch
+        achieved = algo / (k_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("rays") == nrays and tj.get("grid", 0) == grid_n:
+                    traffic = tj["hbm_bytes_per_launch"]
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "ray-steps/sec (whole node) + achieved HBM GB/s vs roofline",
+            "value": tot_steps / tmax,
+            "unit": "accepted ray-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * tmax / max(args.steps, 1),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": wname, "rays_per_gpu": nrays, "grid": grid_n, "maxsteps": p.maxsteps,
+                       "outputper": p.outputper, "integrator": "rkf45 adaptive", "parallelism": "rays sharded x%d" % world,
+                       "gather": bool(dist is not None and not args.no_gather)},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "trace_kernel<%s,adaptive>" % kind, "kernel_ms": k_ms,
+                         "algorithmic_bytes_per_accepted_step": ALGO_BYTES_PER_STEP[kind](p.outputper),
+                         "accepted_steps_per_launch": steps_per_launch},
+            "detail": {"attempts_per_launch": attempts / max(args.steps, 1),
+                       "reject_ratio": 1.0 - steps_acc / max(attempts, 1),
+                       "mean_rows_per_ray": float(nrows.mean()),
+                       "stopcond_hist": {str(int(k)): int(v) for k, v in zip(*np.unique(stop, return_counts=True))},
+                       "model_setup_s": setup_s, "model_device_GB": model.device_bytes / 1e9},
+        }
+        out["cpu_baseline"] = cpu_baseline(args, kind, p, wl, pos0, dir0, w0, grid_n) if args.cpu_seconds > 0 else None
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, kind, p, wl, pos0, dir0, w0, grid_n):
+    """The CPU oracle (a port of the reference's algorithm, oracle/srt_oracle.c) timed on the host cores on
+    a bounded sample of the SAME workload.  Only the checker/baseline leg touches oracle/."""
+    try:
+        from oracle import oracle
+    except Exception as e:  # pragma: no cover
+        return {"error": "oracle unavailable: %s" % e}
+    cores = max(1, min(16, os.cpu_count() or 1))
+    t0 = time.time()
+    if kind == "interp":
+        F, bounds = wl.make_grid(grid_n, half_width=10.0 * wl.R_E)
+        om = oracle.Model.interp(F, bounds, wl.QS, wl.MS)
+        del F
+    else:
+        cfg = os.path.join(tempfile.mkdtemp(), "newray.in")
+        with open(cfg, "w") as f:
+            f.write(wl.NEWRAY_PLASMAPAUSE)
+        om = oracle.Model.ngo(cfg)
+    setup = time.time() - t0
+    kw = dict(dt0=p.dt0, dtmax=p.dtmax, tmax=p.tmax, maxerr=p.maxerr, minalt=p.minalt, del_=p.del_,
+              maxsteps=p.maxsteps, root=p.root, fixedstep=p.fixedstep)
+    # calibrate on a few rays, then size the sample for ~cpu_seconds
+    n0 = min(4 * cores, len(w0))
+    t0 = time.time()
+    _, _, _, s0 = om.trace(pos0[:n0], dir0[:n0], w0[:n0], capacity=0, nthreads=cores, **kw)
+    dt0 = max(time.time() - t0, 1e-3)
+    n1 = int(min(len(w0), max(n0, n0 * args.cpu_seconds / dt0)))
+    t0 = time.time()
+    _, _, _, s1 = om.trace(pos0[:n1], dir0[:n1], w0[:n1], capacity=0, nthreads=cores, **kw)
+    dt1 = time.time() - t0
+    return {"value": s1 / dt1, "unit": "accepted ray-steps/s", "cores": cores, "kind": "port",
+            "sample": "first %d rays of the same launch set, same model and integrator parameters, %d accepted steps in %.1f s "
+                      "(oracle/srt_oracle.c, pthreads over rays; model setup %.1f s excluded)" % (n1, s1, dt1, setup)}
+
+
+if __name__ == "__main__":
+    main()
