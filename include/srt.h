@@ -103,6 +103,9 @@ int srt_plasma_params(srt_model *m, int64_t n, const double *x, double *qs, doub
  * out[n][10] = F, S, D, P, R, L, Re k1, Im k1, Re k2, Im k2   (raytracer.f95:41-102, 408-502) */
 int srt_dispersion(srt_model *m, int64_t n, const double *x, const double *k, const double *w,
                    double *out);
+/* is_right_handed(n2, phi[deg, as the reference passes it], S, D, P) for in[n][5] -> out[n] (0/1)
+ * (raytracer.f95:373-405; model-independent) */
+int srt_is_right_handed(int64_t n, const double *in, int32_t *out);
 /* dFdk(del=1e-8), dFdw(1e-8), dFdx(del), raytracer_evalrhs: out[n][14]  (raytracer.f95:118-314) */
 int srt_gradients(srt_model *m, int64_t n, const double *x, const double *k, const double *w,
                   double del, double *out);
@@ -137,10 +140,12 @@ int srt_last_kernel_ms(srt_model *m, float *ms);
 /* ray input file: 7 list-directed reals per line (raytracer_driver.f95:1146); returns count, fills
  * malloc'd arrays the caller frees with srt_free */
 int64_t srt_read_rays_file(const char *path, double **pos0, double **dir0, double **w0);
-/* .ray writer, record format of raytracer_driver.f95:1197-1217; raynum0 = number of first ray (1) */
+/* .ray writer, record format of raytracer_driver.f95:1197-1217; raynum0 = number of first ray (1).
+ * qs/ms: the model's species constants (srt_model_species); pure host code, needs no GPU. */
 int srt_write_ray_file(const char *path, int append, int64_t raynum0, int64_t nrays,
-                       const srt_params *p, const srt_model *m, const double *w0, const double *rows,
-                       const int32_t *nrows, const int32_t *stopcond);
+                       const srt_params *p, int nspec, const double *qs, const double *ms,
+                       const double *w0, const double *rows, const int32_t *nrows,
+                       const int32_t *stopcond);
 void srt_free(void *p);
 
 #ifdef __cplusplus

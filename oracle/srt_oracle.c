@@ -1158,6 +1158,17 @@ int so_raytracer_run(so_model *m, const so_params *p, const double pos0[3], cons
     lastrefinedown = 0;
     t = t + dtincr;
     nstep = nstep + 1;
+    {
+      /* a non-finite state makes the reference `stop` the whole process inside csvd (blas.f95:208-211,
+         SURVEY A-3); the batch API ends only this ray, with code 9, before the bad row is emitted */
+      int finite = 1;
+      for (int i = 0; i < 6; i++)
+        if (!isfinite(x[i])) finite = 0;
+      if (!finite) {
+        stopcond = 9;
+        break;
+      }
+    }
     emit_row(m, rows, capacity, &nrows, t, x, w, 0, last_vg);
   }
   *nrows_total = nrows;

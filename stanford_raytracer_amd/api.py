@@ -74,6 +74,7 @@ def lib():
     L.srt_model_device_bytes.restype = C.c_int64
     L.srt_plasma_params.argtypes = [vp, C.c_int64, dp, dp, dp, dp, dp, dp]
     L.srt_dispersion.argtypes = [vp, C.c_int64, dp, dp, dp, dp]
+    L.srt_is_right_handed.argtypes = [C.c_int64, dp, ip]
     L.srt_gradients.argtypes = [vp, C.c_int64, dp, dp, dp, C.c_double, dp]
     L.srt_rk_step.argtypes = [vp, C.c_int64, dp, dp, C.c_double, dp]
     L.srt_rows_per_ray.argtypes = [C.POINTER(Params)]
@@ -83,7 +84,8 @@ def lib():
     L.srt_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.srt_read_rays_file.argtypes = [C.c_char_p, C.POINTER(dp), C.POINTER(dp), C.POINTER(dp)]
     L.srt_read_rays_file.restype = C.c_int64
-    L.srt_write_ray_file.argtypes = [C.c_char_p, C.c_int, C.c_int64, C.c_int64, C.POINTER(Params), vp, dp, dp, ip, ip]
+    L.srt_write_ray_file.argtypes = [C.c_char_p, C.c_int, C.c_int64, C.c_int64, C.POINTER(Params), C.c_int, dp, dp,
+                                     dp, dp, ip, ip]
     L.srt_free.argtypes = [vp]
     L.srt_free.restype = None
     _lib = L
@@ -232,6 +234,14 @@ class Model:
         return ms.value
 
 
+def is_right_handed(rows):
+    """rows[n,5] = n2, phi (degrees, as the reference passes it), S, D, P -> bool[n]."""
+    rows = _f64(rows, (-1, 5))
+    out = np.zeros(rows.shape[0], dtype=np.int32)
+    _check(lib().srt_is_right_handed(rows.shape[0], _dp(rows), out.ctypes.data_as(ip)))
+    return out.astype(bool)
+
+
 def read_rays_file(path):
     a, b, c = dp(), dp(), dp()
     n = lib().srt_read_rays_file(os.fsencode(path), C.byref(a), C.byref(b), C.byref(c))
@@ -245,10 +255,18 @@ def read_rays_file(path):
     return pos0, dir0, w0
 
 
-def write_ray_file(path, model, params, w0, rows, nrows, stopcond, raynum0=1, append=False):
+def write_ray_file(path, species, params, w0, rows, nrows, stopcond, raynum0=1, append=False):
+    """species: a Model, or (nspec, qs, ms)."""
+    if isinstance(species, Model):
+        qs, ms = species.species()
+        nspec = species.nspec
+    else:
+        nspec, qs, ms = species
+        qs, ms = _f64(qs), _f64(ms)
     w0 = _f64(w0, (-1,))
     rows = _f64(rows)
     nrows = np.ascontiguousarray(nrows, dtype=np.int32)
     stopcond = np.ascontiguousarray(stopcond, dtype=np.int32)
-    _check(lib().srt_write_ray_file(os.fsencode(path), int(append), raynum0, w0.shape[0], C.byref(params), model.h,
-                                    _dp(w0), _dp(rows), nrows.ctypes.data_as(ip), stopcond.ctypes.data_as(ip)))
+    _check(lib().srt_write_ray_file(os.fsencode(path), int(append), raynum0, w0.shape[0], C.byref(params), nspec,
+                                    _dp(qs), _dp(ms), _dp(w0), _dp(rows), nrows.ctypes.data_as(ip),
+                                    stopcond.ctypes.data_as(ip)))

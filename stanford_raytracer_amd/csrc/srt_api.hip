@@ -473,6 +473,22 @@ extern "C" int srt_dispersion(srt_model *m, int64_t n, const double *x, const do
   return SRT_OK;
 }
 
+extern "C" int srt_is_right_handed(int64_t n, const double *in, int32_t *out) {
+  if (!in || !out || n < 0) return srt_set_error(SRT_EINVAL, "bad argument");
+  if (n == 0) return SRT_OK;
+  int rc = ensure_init();
+  if (rc) return rc;
+  DevBuf din;
+  if ((rc = upload(din, in, 5 * n))) return rc;
+  int *d_out = nullptr;
+  HIP_OK(hipMalloc(&d_out, n * sizeof(int)));
+  hipLaunchKernelGGL(handedness_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, (long long)n, (const double *)din.p, d_out);
+  hipError_t e = hipMemcpy(out, d_out, n * sizeof(int), hipMemcpyDeviceToHost);
+  (void)hipFree(d_out);
+  if (e != hipSuccess) return srt_set_error(SRT_EDEVICE, "handedness kernel: %s", hipGetErrorString(e));
+  return SRT_OK;
+}
+
 extern "C" int srt_gradients(srt_model *m, int64_t n, const double *x, const double *k, const double *w, double del, double *out) {
   if (!m || !x || !k || !w || !out || n < 0) return srt_set_error(SRT_EINVAL, "bad argument");
   if (n == 0) return SRT_OK;

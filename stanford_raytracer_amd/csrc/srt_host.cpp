@@ -190,18 +190,16 @@ extern "C" int64_t srt_read_rays_file(const char *path, double **pos0, double **
 //   (i10, i10, 17es24.15e3, i10) raynum, stopcond, t, pos, vprel, vgrel, n, B0, w, nspec
 //   then nspec x es24.15e3 for each of qs, ms, Ns, nus
 extern "C" int srt_write_ray_file(const char *path, int append, int64_t raynum0, int64_t nrays, const srt_params *p,
-                                  const srt_model *m, const double *w0, const double *rows, const int32_t *nrows,
-                                  const int32_t *stopcond) {
-  if (!path || !p || !m || !w0 || !rows || !nrows || !stopcond) return srt_set_error(SRT_EINVAL, "null argument");
+                                  int nspec, const double *qs, const double *ms, const double *w0,
+                                  const double *rows, const int32_t *nrows, const int32_t *stopcond) {
+  if (!path || !p || !qs || !ms || !w0 || !rows || !nrows || !stopcond) return srt_set_error(SRT_EINVAL, "null argument");
+  if (nspec < 1 || nspec > SRT_MAXSPEC) return srt_set_error(SRT_EINVAL, "nspec out of range");
   FILE *f = fopen(path, append ? "a" : "w");
   if (!f) return srt_set_error(SRT_EIO, "%s: cannot open for writing", path);
   std::vector<char> big(1 << 22);
   setvbuf(f, big.data(), _IOFBF, big.size());
   const int slots = srt_rows_per_ray(p);
   const int per = p->outputper < 1 ? 1 : p->outputper;
-  const int nspec = srt_model_nspec(m);
-  double qs[4], ms[4];
-  srt_model_species(m, qs, ms);
   char qsbuf[4][25], msbuf[4][25], zero[25], num[25];
   for (int s = 0; s < nspec; ++s) {
     srt_host::format_es24(qs[s], qsbuf[s]);

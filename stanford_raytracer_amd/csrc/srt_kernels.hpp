@@ -412,6 +412,16 @@ __global__ __launch_bounds__(64) void trace_kernel(const M *__restrict__ mp, con
         lastrefinedown = 0;
         t = t + dtincr;
         nstep = nstep + 1;
+        // a non-finite state makes the reference die in zgesvd (`stop`, blas.f95:208-211); end this ray only
+        bool finite = true;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) finite = finite && isfinite(x[c]);
+        if (!finite) {
+          a.nrows[ray] = nstep - 1;
+          a.stopcond[ray] = 9;
+          acc_steps += (unsigned long long)(nstep - 2);
+          active = false;
+        }
         double dk[3], dw;
         group_terms(cm, ps2, x + 3, w, dk, dw);
         double cw = cm.C / w;
@@ -424,7 +434,7 @@ __global__ __launch_bounds__(64) void trace_kernel(const M *__restrict__ mp, con
           vg[c] = -(dk[c] / dw) / cm.C;
         }
         const int row = nstep - 1;
-        if (row % P.outputper == 0) {
+        if (finite && row % P.outputper == 0) {
           int slot = row / P.outputper;
           if (slot < P.slots)
             store_row(a.rows + ((size_t)ray * (size_t)P.slots + (size_t)slot) * ROW, t, x, vp, vg, n, ps2);
@@ -498,6 +508,11 @@ __global__ __launch_bounds__(64) void dispersion_kernel(const M *__restrict__ mp
     o[0] = F; o[1] = st.S; o[2] = st.D; o[3] = st.P; o[4] = st.R; o[5] = st.L;
     o[6] = rt.k1re; o[7] = rt.k1im; o[8] = rt.k2re; o[9] = rt.k2im;
   }
+}
+
+__global__ void handedness_kernel(long long n, const double *in, int *out) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = is_right_handed(in[5 * i], in[5 * i + 1], in[5 * i + 2], in[5 * i + 3], in[5 * i + 4]) ? 1 : 0;
 }
 
 // out[n][14] = dFdk(3), dFdw, dFdx(3), rhs(7)

@@ -1,0 +1,66 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs an MI355X (run on the GPU box with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return np.load(os.path.join(GOLDEN_DIR, "golden.npz"))
+
+
+@pytest.fixture(scope="session")
+def grid16():
+    g = np.load(os.path.join(GOLDEN_DIR, "grid16.npz"))
+    return g["F"], g["bounds"], g["qs"], g["ms"]
+
+
+@pytest.fixture(scope="session")
+def cfgfiles(tmp_path_factory):
+    from stanford_raytracer_amd import workloads as wl
+
+    d = tmp_path_factory.mktemp("cfg")
+    out = {}
+    for name, text in (("ngo", wl.NEWRAY_PLASMAPAUSE), ("ngoducts", wl.NEWRAY_DUCTS)):
+        p = d / ("newray_%s.in" % name)
+        p.write_text(text)
+        out[name] = str(p)
+    return out
+
+
+@pytest.fixture(scope="session")
+def oracle_models(cfgfiles, grid16):
+    from oracle import oracle
+
+    F, b, qs, ms = grid16
+    return {"ngo": oracle.Model.ngo(cfgfiles["ngo"]), "ngoducts": oracle.Model.ngo(cfgfiles["ngoducts"]),
+            "interp": oracle.Model.interp(F, b, qs, ms)}
+
+
+@pytest.fixture(scope="session")
+def gpu_models(cfgfiles, grid16):
+    from stanford_raytracer_amd import api
+
+    api.init(0)
+    F, b, qs, ms = grid16
+    return {"ngo": api.Model.ngo(cfgfiles["ngo"]), "ngoducts": api.Model.ngo(cfgfiles["ngoducts"]),
+            "interp": api.Model.interp(F, b, qs, ms)}
+
+
+DELS = {"ngo": 1e-4, "ngoducts": 1e-4, "interp": 1e-6}
+
+
+def vrel(a, b):
+    """|a-b| / |b| over the last axis (vector-relative error)."""
+    a, b = np.asarray(a), np.asarray(b)
+    return np.linalg.norm(a - b, axis=-1) / np.maximum(np.linalg.norm(b, axis=-1), 1e-300)

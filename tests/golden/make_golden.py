@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ from the REAL reference.
+
+Run in the build container only (needs oracle/_ref/ref_harness, built from /root/reference by
+oracle/build_ref.py with AMD flang -O3; compiler line recorded in each fixture).  The fixtures are
+data: the inputs we authored (the reference ships none) and the reference's
+outputs for them, captured layer by layer.
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import refharness  # noqa: E402
+from stanford_raytracer_amd import workloads as wl  # noqa: E402
+
+RUN_KW = dict(dt0=1e-3, dtmax=0.1, maxerr=5e-4, maxsteps=2000, minalt=wl.MINALT, root=2)
+
+
+def compact(rows32):
+    """32-column reference rows -> the 20 columns that vary (t,pos,vprel,vgrel,n,B0,Ns)."""
+    return np.concatenate([rows32[:, :16], rows32[:, 24:28]], axis=1)
+
+
+def states_on_surface(model, pos, d, w):
+    """k on the whistler root along direction d, via the reference's own solve_dispersion_relation."""
+    rows = np.concatenate([pos, d, w[:, None]], axis=1)
+    out = refharness.run_mode("disp", rows, model)
+    ok = out[:, 8] > 0
+    return pos[ok], out[ok, 8:9] * d[ok], w[ok]
+
+
+def run_set(model, pos0, dir0, w0, tag, store, rayout=None, **kw):
+    rays = np.concatenate([pos0, dir0, w0[:, None]], axis=1)
+    args = dict(RUN_KW)
+    args.update(kw)
+    out, _ = refharness.run_rays(model, rays, rayout=rayout, **args)
+    T = max(o["rows"].shape[0] for o in out)
+    rows = np.zeros((len(out), T, 20))
+    nrows = np.zeros(len(out), dtype=np.int32)
+    stop = np.zeros(len(out), dtype=np.int32)
+    for i, o in enumerate(out):
+        r = compact(o["rows"])
+        rows[i, :r.shape[0]] = r
+        nrows[i] = r.shape[0]
+        stop[i] = o["stopcond"]
+    store[tag + "_rows"] = rows
+    store[tag + "_nrows"] = nrows
+    store[tag + "_stop"] = stop
+    store[tag + "_params"] = np.array([args["dt0"], args["dtmax"], args.get("tmax", 1.0), args["maxerr"], args["minalt"],
+                                       args["maxsteps"], args["root"], args.get("fixedstep", 0)])
+
+
+def main():
+    if not refharness.available():
+        raise SystemExit("oracle/_ref/ref_harness missing: run python oracle/build_ref.py first")
+    info = open(os.path.join(ROOT, "oracle", "_ref", "BUILD_INFO.txt")).read()
+    work = os.path.join(HERE, "_work")
+    os.makedirs(work, exist_ok=True)
+    # ---- inputs we author
+    cfg_pp = os.path.join(work, "newray_plasmapause.in")
+    cfg_du = os.path.join(work, "newray_ducts.in")
+    open(cfg_pp, "w").write(wl.NEWRAY_PLASMAPAUSE)
+    open(cfg_du, "w").write(wl.NEWRAY_DUCTS)
+    F, bounds = wl.make_grid(16, half_width=5.0 * wl.R_E)
+    gridfile = os.path.join(work, "grid16.txt")
+    wl.write_grid_file(gridfile, F, bounds)
+    np.savez_compressed(os.path.join(HERE, "grid16.npz"), F=F, bounds=bounds, qs=wl.QS, ms=wl.MS)
+    models = {
+        "ngo": {"kind": 1, "file": cfg_pp},
+        "ngoducts": {"kind": 1, "file": cfg_du},
+        "interp": {"kind": 3, "file": gridfile},
+    }
+    dels = {"ngo": 1e-4, "ngoducts": 1e-4, "interp": 1e-6}
+    rng = np.random.default_rng(20260101)
+    store = {"build_info": np.array(info)}
+
+    # ---- G0: funcPlasmaParams
+    pos, d, w = wl.launch_set(160, 101)
+    ax = np.arange(16) * ((10 * wl.R_E) / 15.0) + (-5 * wl.R_E)
+    edge = np.array([[ax[3], ax[4], ax[5]], [ax[15], ax[8], ax[8]], [ax[0], ax[0], ax[0]], [6 * wl.R_E, 0, 0],
+                     [-6 * wl.R_E, 1e6, 2e6], [0, 7 * wl.R_E, -7 * wl.R_E], [ax[15] + 1, ax[15] - 1, ax[14] + 5],
+                     [ax[0] - 1, ax[1], ax[2] + 3], [ax[15], ax[15], ax[15]], [ax[7], ax[15], ax[0] - 10]])
+    wide = rng.uniform(-5.6 * wl.R_E, 5.6 * wl.R_E, (60, 3))
+    for name, mdl in models.items():
+        x = np.concatenate([pos, edge, wide]) if name == "interp" else np.concatenate([pos, wide[:20]])
+        store["g0_%s_x" % name] = x
+        store["g0_%s_out" % name] = refharness.run_mode("params", x, mdl)
+
+    # ---- G1: dispersion relation, Stix parameters, both roots; is_right_handed
+    for name, mdl in models.items():
+        p_, d_, w_ = wl.launch_set(200, 202)
+        rows = np.concatenate([p_, d_ * 1e-3, w_[:, None]], axis=1)  # arbitrary |k|: exercises F != 0
+        xs, ks, ws = states_on_surface(mdl, p_, d_, w_)
+        rows = np.concatenate([rows, np.concatenate([xs, ks, ws[:, None]], axis=1)])
+        store["g1_%s_in" % name] = rows
+        store["g1_%s_out" % name] = refharness.run_mode("disp", rows, mdl)
+    n = 3000
+    S = -10.0 ** rng.uniform(0, 3, n)
+    D = 10.0 ** rng.uniform(1, 4, n) * rng.choice([-1.0, 1.0], n)
+    P = -10.0 ** rng.uniform(3, 7, n)
+    n2 = 10.0 ** rng.uniform(0, 4, n) * rng.choice([1.0, 1.0, 1.0, -1.0], n)
+    phi = rng.uniform(0.0, 90.0, n)
+    rh_in = np.stack([n2, phi, S, D, P], axis=1)
+    store["g1_rh_in"] = rh_in
+    store["g1_rh_out"] = refharness.run_mode("rh", rh_in)[:, 0]
+
+    # ---- G2 / G3: gradients and single RK steps at on-surface states
+    for name, mdl in models.items():
+        p_, d_, w_ = wl.launch_set(140, 303)
+        xs, ks, ws = states_on_surface(mdl, p_, d_, w_)
+        xs, ks, ws = xs[:100], ks[:100], ws[:100]
+        g_in = np.concatenate([xs, ks, ws[:, None], np.full((len(ws), 1), dels[name])], axis=1)
+        store["g2_%s_in" % name] = g_in
+        store["g2_%s_out" % name] = refharness.run_mode("grad", g_in, mdl)
+        s_in = np.concatenate([xs[:48], ks[:48], ws[:48, None], np.full((48, 1), 1e-3), np.full((48, 1), dels[name])], axis=1)
+        store["g3_%s_in" % name] = s_in
+        store["g3_%s_out" % name] = refharness.run_mode("step", s_in, mdl)
+
+    # ---- G4: whole trajectories
+    p0, d0, w0 = wl.appendix_b_rays()
+    store["g4_rays"] = np.concatenate([p0, d0, w0[:, None]], axis=1)
+    # config 1 of BASELINE.json: 16 rays, Ngo, fixed RK4 (the reference's own CPU-runnable case)
+    run_set(models["ngo"], p0, d0, w0, "g4_ngo_fixed", store, rayout=os.path.join(work, "config1.ray"),
+            fixedstep=1, tmax=0.1, outputper=25)
+    run_set(models["ngo"], p0, d0, w0, "g4_ngo_adaptive", store, fixedstep=0, tmax=0.4)
+    run_set(models["ngoducts"], p0, d0, w0, "g4_ngoducts_adaptive", store, fixedstep=0, tmax=0.2)
+    run_set(models["interp"], p0, d0, w0, "g4_interp_fixed", store, fixedstep=1, tmax=0.05)
+    run_set(models["interp"], p0, d0, w0, "g4_interp_adaptive", store, fixedstep=0, tmax=0.02, maxsteps=120)
+    # field-aligned launches (dir0 = 0) and rays that stop at once (evanescent start)
+    lp, ld, lw = wl.launch_set(24, 404)
+    ld0 = np.zeros_like(ld)
+    store["g4_fa_rays"] = np.concatenate([lp, ld0, lw[:, None]], axis=1)
+    run_set(models["ngo"], lp, ld0, lw, "g4_ngo_fieldaligned", store, fixedstep=0, tmax=0.05)
+    # the reference process dies on the first ray whose cos^2(phi) rounds above 1 (SVD of a NaN matrix ->
+    # `stop`, blas.f95:208-211; SURVEY A-2/A-3): keep the rays it finished
+    store["g4_fa_rays"] = store["g4_fa_rays"][:len(store["g4_ngo_fieldaligned_nrows"])]
+    # a general launch set with explicit directions: includes rays that stop on their first test (k = 0)
+    store["g4_launch_rays"] = np.concatenate([lp, ld, lw[:, None]], axis=1)
+    run_set(models["ngo"], lp, ld, lw, "g4_ngo_launch", store, fixedstep=0, tmax=0.05)
+    run_set(models["interp"], lp, ld, lw, "g4_interp_launch", store, fixedstep=0, tmax=0.02, maxsteps=100)
+    # the text .ray file of config 1 (record format of raytracer_driver.f95:1197-1217)
+    with open(os.path.join(work, "config1.ray")) as f:
+        text = f.read()
+    with open(os.path.join(HERE, "config1_outputper25.ray"), "w") as f:
+        f.write(text)
+    np.savez_compressed(os.path.join(HERE, "golden.npz"), **store)
+    print("wrote", os.path.join(HERE, "golden.npz"), "%.1f KB" % (os.path.getsize(os.path.join(HERE, "golden.npz")) / 1e3))
+    for f in os.listdir(work):
+        os.remove(os.path.join(work, f))
+    os.rmdir(work)
+
+
+if __name__ == "__main__":
+    main()

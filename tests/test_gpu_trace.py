@@ -1,0 +1,233 @@
+"""GPU (-m gpu): whole trajectories (raytracer_run batched) against the oracle / golden vectors, edge cases,
+and size-independent properties at BASELINE.json's full sizes.
+
+Trajectories are chaotic at rounding level: the reference diverges from its own FMA rebuild by 1.2e-10 /
+7e-8 / 4e-5 in position after 1 / 10 / 100 fixed steps and changes adaptive step sequences within 2-22 steps
+(SURVEY A-9).  The bar used here: the GPU's divergence from the oracle must not exceed 10x the oracle's
+own divergence under a 1e-9 relative shift of the launch point (~1 cm), with the survey ladder x10 as floor.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import DELS, vrel
+from stanford_raytracer_amd import workloads as wl
+
+pytestmark = pytest.mark.gpu
+LADDER = {1: 1.2e-10, 10: 7e-8, 100: 4e-5}
+
+
+def divergence(ra, na, rb, nb, r, cols):
+    sel = (na > r) & (nb > r)
+    if not sel.any():
+        return 0.0
+    return float(vrel(ra[sel, r][:, cols], rb[sel, r][:, cols]).max())
+
+
+def oracle_yardstick(om, rays, kw, rows_at, cap):
+    base = om.trace(rays[:, :3], rays[:, 3:6], rays[:, 6], capacity=cap, **kw)
+    out = {r: 0.0 for r in rows_at}
+    for eps in (1e-9, -1e-9):
+        pert = om.trace(rays[:, :3] * (1 + eps), rays[:, 3:6], rays[:, 6], capacity=cap, **kw)
+        for r in rows_at:
+            out[r] = max(out[r], divergence(pert[0], pert[1], base[0], base[1], r, slice(1, 4)))
+    return base, out
+
+
+@pytest.mark.parametrize("name,tag,rows_at", [("ngo", "g4_ngo_fixed", (1, 10, 100)), ("interp", "g4_interp_fixed", (1, 10, 50))])
+def test_fixed_step_trajectories(golden, gpu_models, oracle_models, name, tag, rows_at):
+    """BASELINE config[0] shape: 16 rays, fixed RK4.  Compared with the reference's golden rows."""
+    rays, prm = golden["g4_rays"], golden[tag + "_params"]
+    ref_rows, ref_n, ref_stop = golden[tag + "_rows"], golden[tag + "_nrows"], golden[tag + "_stop"]
+    kw = dict(dt0=prm[0], dtmax=prm[1], tmax=prm[2], maxerr=prm[3], minalt=prm[4], maxsteps=int(prm[5]),
+              root=int(prm[6]), fixedstep=1, del_=DELS[name])
+    cap = int(ref_rows.shape[1])
+    rows, nrows, stop, steps = gpu_models[name].trace(rays[:, :3], rays[:, 3:6], rays[:, 6], outputper=1,
+                                                      **dict(kw, maxsteps=cap + 1))
+    assert np.array_equal(nrows, ref_n) and np.array_equal(stop, ref_stop)
+    assert steps == int((ref_n - 1).sum())
+    # row 0 is a pure function of the inputs
+    assert np.array_equal(rows[:, 0, 0:4], ref_rows[:, 0, 0:4])
+    assert vrel(rows[:, 0, 13:16], ref_rows[:, 0, 13:16]).max() <= 2e-7
+    assert vrel(rows[:, 0, 10:13], ref_rows[:, 0, 10:13]).max() <= 1e-10
+    assert vrel(rows[:, 0, 7:10], ref_rows[:, 0, 7:10]).max() <= 1e-6   # vgrel: pure finite differences
+    _, yard = oracle_yardstick(oracle_models[name], rays, dict(kw, maxsteps=cap + 1), rows_at, cap)
+    for r in rows_at:
+        d = divergence(rows, nrows, ref_rows, ref_n, r, slice(1, 4))
+        bound = 10 * max(yard[r], LADDER.get(r, 4e-5))
+        assert d <= bound, "row %d: position divergence %.2e > %.2e" % (r, d, bound)
+        assert np.allclose(rows[:, r, 0], ref_rows[:, r, 0], rtol=1e-12)  # same time grid
+
+
+def curve_distance(rows_a, n_a, rows_b, n_b, tmax):
+    """max over rays of the relative distance between the two position curves on a common time grid."""
+    worst = 0.0
+    for i in range(rows_a.shape[0]):
+        ta, tb = rows_a[i, :n_a[i], 0], rows_b[i, :n_b[i], 0]
+        if len(ta) < 3 or len(tb) < 3:
+            continue
+        tt = np.linspace(0, min(ta[-1], tb[-1], tmax), 20)
+        pa = np.stack([np.interp(tt, ta, rows_a[i, :n_a[i], 1 + c]) for c in range(3)], axis=1)
+        pb = np.stack([np.interp(tt, tb, rows_b[i, :n_b[i], 1 + c]) for c in range(3)], axis=1)
+        worst = max(worst, float(vrel(pa, pb).max()))
+    return worst
+
+
+@pytest.mark.parametrize("name,tag", [("ngo", "g4_ngo_adaptive"), ("ngoducts", "g4_ngoducts_adaptive"),
+                                      ("interp", "g4_interp_adaptive"), ("ngo", "g4_ngo_launch"),
+                                      ("interp", "g4_interp_launch")])
+def test_adaptive_trajectories(golden, gpu_models, name, tag):
+    rays = golden["g4_launch_rays" if tag.endswith("launch") else "g4_rays"]
+    prm = golden[tag + "_params"]
+    ref_rows, ref_n, ref_stop = golden[tag + "_rows"], golden[tag + "_nrows"], golden[tag + "_stop"]
+    rows, nrows, stop, _ = gpu_models[name].trace(rays[:, :3], rays[:, 3:6], rays[:, 6], outputper=1, dt0=prm[0],
+                                                  dtmax=prm[1], tmax=prm[2], maxerr=prm[3], minalt=prm[4],
+                                                  maxsteps=int(prm[5]), root=int(prm[6]), fixedstep=0, del_=DELS[name])
+    assert np.mean(stop == ref_stop) >= 0.9
+    # first attempt: always accepted at dt0 and never grown (SURVEY A-1, flang semantics); the second
+    # step therefore ends at 2 dt0 at the latest
+    both = (nrows > 2) & (ref_n > 2)
+    assert np.allclose(rows[both, 1, 0], prm[0]) and np.all(rows[both, 2, 0] <= 2 * prm[0] * (1 + 1e-12))
+    assert abs(int(nrows.sum()) - int(ref_n.sum())) <= 0.15 * ref_n.sum()
+    # curves: position on a common time grid over the early part of the run
+    assert curve_distance(rows, nrows, ref_rows, ref_n, 0.1) <= (1e-3 if name != "interp" else 2e-2)
+
+
+def test_field_aligned_launch(golden, gpu_models):
+    """dir0 = 0 -> start along B with the radial component made positive (raytracer.f95:661-674)."""
+    rays, prm = golden["g4_fa_rays"], golden["g4_ngo_fieldaligned_params"]
+    ref_rows, ref_n = golden["g4_ngo_fieldaligned_rows"], golden["g4_ngo_fieldaligned_nrows"]
+    rows, nrows, stop, _ = gpu_models["ngo"].trace(rays[:, :3], rays[:, 3:6], rays[:, 6], outputper=1, dt0=prm[0],
+                                                   dtmax=prm[1], tmax=prm[2], maxerr=prm[3], minalt=prm[4],
+                                                   maxsteps=int(prm[5]), root=2, fixedstep=0, del_=1e-4)
+    assert vrel(rows[:, 0, 10:13], ref_rows[:, 0, 10:13]).max() <= 1e-9   # n0 = k0 c / w along B
+    assert curve_distance(rows, nrows, ref_rows, ref_n, 0.05) <= 1e-3
+
+
+def test_edge_cases(gpu_models):
+    from stanford_raytracer_amd import api
+
+    m = gpu_models["ngo"]
+    pos, d, w = wl.launch_set(65, 31)
+    kw = dict(fixedstep=0, dt0=1e-3, dtmax=0.1, maxerr=5e-4, tmax=0.02, del_=1e-4)
+    # empty batch
+    rows, nrows, stop, steps = m.trace(pos[:0], d[:0], w[:0], maxsteps=8, **kw)
+    assert rows.shape[0] == 0 and steps == 0
+    # maxsteps = 1: only row 0, stop code 6 unless an earlier test fires
+    rows, nrows, stop, steps = m.trace(pos, d, w, maxsteps=1, **kw)
+    assert np.all(nrows == 1) and steps == 0 and set(stop.tolist()) <= {1, 2, 6}
+    assert np.array_equal(rows[:, 0, 1:4], pos)
+    # tmax = 0: normal exit before any step
+    rows, nrows, stop, _ = m.trace(pos, d, w, maxsteps=8, **dict(kw, tmax=0.0))
+    assert np.all(nrows == 1) and np.all(stop == 0)
+    # launch below minalt -> stop 1 on the first test
+    low = pos.copy()
+    low *= (wl.R_E + 50e3) / np.linalg.norm(low, axis=1, keepdims=True)
+    _, nrows, stop, _ = m.trace(low, d, w, maxsteps=8, **kw)
+    assert np.all(stop == 1) and np.all(nrows == 1)
+    # outputper larger than the trajectory: one kept row
+    rows, nrows, stop, _ = m.trace(pos, d, w, maxsteps=16, outputper=64, **kw)
+    assert rows.shape[1] == 1
+    # bad arguments are rejected, not run
+    for bad in (dict(maxsteps=0), dict(root=3), dict(del_=0.0)):
+        with pytest.raises(api.SrtError):
+            m.trace(pos, d, w, **dict(dict(kw, maxsteps=8), **bad))
+
+
+def test_evanescent_starts_stop_at_once(gpu_models, oracle_models):
+    """Rays whose chosen root is evanescent at the launch point get k0 = Re(k) = 0 and stop with code 2 on
+    the first test (raytracer.f95:690, :334); which rays those are is decided before any FD noise enters."""
+    pos, d, w = wl.launch_set(2000, 77)
+    kw = dict(fixedstep=0, dt0=1e-3, dtmax=0.1, maxerr=5e-4, tmax=0.004, maxsteps=6, del_=1e-4)
+    _, nrows, stop, _ = gpu_models["ngo"].trace(pos, d, w, **kw)
+    _, on, ostop, _ = oracle_models["ngo"].trace(pos, d, w, capacity=0, **kw)
+    assert (ostop == 2).sum() > 20
+    assert np.array_equal(stop == 2, ostop == 2)
+    assert np.all(nrows[stop == 2] == 1)
+    assert np.mean(stop == ostop) > 0.98
+
+
+def test_interp_rays_outside_the_grid(gpu_models, oracle_models):
+    """Rays launched beyond the grid bounds run on the clamped edge cells like the reference's."""
+    g, o = gpu_models["interp"], oracle_models["interp"]
+    pos, d, w = wl.launch_set(48, 55)
+    pos = pos * (5.3 * wl.R_E / np.abs(pos).max(axis=1, keepdims=True))  # one coordinate beyond +-5 R_E
+    kw = dict(fixedstep=1, dt0=1e-3, tmax=0.003, maxsteps=8, del_=1e-6)
+    rows, nrows, stop, _ = g.trace(pos, d, w, **kw)
+    orows, on, ostop, _ = o.trace(pos, d, w, capacity=8, **kw)
+    assert np.array_equal(stop, ostop) and np.array_equal(nrows, on)
+    sel = nrows > 1
+    assert vrel(rows[sel, 1, 1:4], orows[sel, 1, 1:4]).max() <= 1e-7
+    assert np.max(np.abs(rows[:, 0, 16:20] - orows[:, 0, 16:20]) / orows[:, 0, 16:20]) <= 1e-11
+
+
+@pytest.mark.parametrize("name", ["ngo", "interp"])
+def test_determinism_and_lane_independence(gpu_models, name):
+    """A ray's result must not depend on which lane/wave integrates it, nor on the refill policy."""
+    m = gpu_models[name]
+    pos, d, w = wl.launch_set(3000, 91)
+    kw = dict(fixedstep=0, dt0=1e-3, dtmax=0.1, maxerr=5e-4, tmax=0.05, maxsteps=40, outputper=8, del_=DELS[name])
+    a = m.trace(pos, d, w, **kw)
+    b = m.trace(pos, d, w, **kw)
+    assert all(np.array_equal(x, y) for x, y in zip(a[:3], b[:3])) and a[3] == b[3]
+    perm = np.random.default_rng(1).permutation(len(w))
+    c = m.trace(pos[perm], d[perm], w[perm], **kw)
+    assert np.array_equal(c[0], a[0][perm]) and np.array_equal(c[1], a[1][perm]) and np.array_equal(c[2], a[2][perm])
+    e = m.trace(pos, d, w, refill_threshold=48, **kw)
+    assert all(np.array_equal(x, y) for x, y in zip(a[:3], e[:3]))
+
+
+def check_invariants(pos, rows, nrows, stop, steps, p):
+    slots = rows.shape[1]
+    assert steps == int(nrows.astype(np.int64).sum() - len(nrows))
+    assert nrows.min() >= 1 and nrows.max() <= p.maxsteps
+    assert set(np.unique(stop).tolist()) <= {0, 1, 2, 3, 5, 6, 9}
+    assert np.mean(stop == 9) < 0.01
+    assert np.all(nrows[stop == 6] == p.maxsteps)
+    assert np.array_equal(rows[:, 0, 1:4], pos) and np.all(rows[:, 0, 0] == 0)
+    kept = np.minimum((nrows + p.outputper - 1) // p.outputper, slots)
+    for s in range(1, slots):
+        live = kept > s
+        if live.any():
+            assert np.all(rows[live, s, 0] > rows[live, s - 1, 0])  # time strictly increases
+            assert np.all(np.isfinite(rows[live, s, 1:4]))          # non-finite states end with code 9 at once
+    done = (stop == 0) & (kept >= 1)
+    return done
+
+
+def test_full_size_config2_ngo_100k(cfgfiles):
+    """BASELINE config[1]: 100k rays, Ngo, adaptive RK45 -- size-independent properties."""
+    from stanford_raytracer_amd import api
+
+    m = api.Model.ngo(cfgfiles["ngo"])
+    pos, d, w = wl.launch_set(100_000, 2)
+    p = api.make_params(fixedstep=0, dt0=1e-3, dtmax=0.1, maxerr=5e-4, tmax=0.5, maxsteps=512, outputper=8, del_=1e-4,
+                        minalt=wl.MINALT)
+    rows, nrows, stop, steps = m.trace(pos, d, w, params=p)
+    check_invariants(pos, rows, nrows, stop, steps, p)
+    assert steps > 1_000_000
+    # a shuffled subset reproduces the same rays bit for bit (lane independence at scale)
+    idx = np.random.default_rng(5).choice(len(w), 4096, replace=False)
+    r2, n2, s2, _ = m.trace(pos[idx], d[idx], w[idx], params=p)
+    assert np.array_equal(r2, rows[idx]) and np.array_equal(n2, nrows[idx]) and np.array_equal(s2, stop[idx])
+
+
+def test_full_size_config3_interp256_1m():
+    """BASELINE config[2]: 1M rays on the 256^3 grid (34.8 GB coefficient table) -- properties only."""
+    from stanford_raytracer_amd import api
+
+    F, b = wl.make_grid(256, half_width=10.0 * wl.R_E)
+    m = api.Model.interp(F, b, wl.QS, wl.MS)
+    del F
+    assert m.device_bytes == 257 ** 3 * 4 * 64 * 8
+    pos, d, w = wl.launch_set(1_000_000, 3)
+    p = api.make_params(fixedstep=0, dt0=1e-3, dtmax=0.1, maxerr=5e-4, tmax=0.5, maxsteps=256, outputper=128, del_=1e-6,
+                        minalt=wl.MINALT)
+    rows, nrows, stop, steps = m.trace(pos, d, w, params=p)
+    check_invariants(pos, rows, nrows, stop, steps, p)
+    assert steps > 100_000_000
+    idx = np.random.default_rng(6).choice(len(w), 8192, replace=False)
+    r2, n2, s2, _ = m.trace(pos[idx], d[idx], w[idx], params=p)
+    assert np.array_equal(r2, rows[idx]) and np.array_equal(n2, nrows[idx]) and np.array_equal(s2, stop[idx])
+    m.close()

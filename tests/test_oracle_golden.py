@@ -1,0 +1,99 @@
+"""CPU: the oracle (oracle/srt_oracle.c) against the golden vectors captured from the real reference
+(tests/golden/make_golden.py).  In this image the restatement is bit-identical to the flang build of the
+reference; the assertions allow 1e-13 so a different host libm does not turn into a false alarm, and
+report exactness separately."""
+import numpy as np
+import pytest
+
+from conftest import DELS
+
+MODELS = ["ngo", "ngoducts", "interp"]
+RTOL = 1e-13
+
+
+def close(a, b, rtol=RTOL):
+    a, b = np.asarray(a), np.asarray(b)
+    both_nan = np.isnan(a) & np.isnan(b)
+    return np.all(both_nan | (np.abs(a - b) <= rtol * np.abs(b)) | (a == b))
+
+
+@pytest.mark.parametrize("name", MODELS)
+def test_g0_plasma_params(golden, oracle_models, name):
+    m = oracle_models[name]
+    x, ref = golden["g0_%s_x" % name], golden["g0_%s_out" % name]
+    mine = np.array([np.concatenate(m.plasma_params(p)) for p in x])
+    assert close(mine, ref)
+    assert np.mean(mine == ref) > 0.999
+
+
+@pytest.mark.parametrize("name", MODELS)
+def test_g1_dispersion(golden, oracle_models, name):
+    m = oracle_models[name]
+    rows, ref = golden["g1_%s_in" % name], golden["g1_%s_out" % name]
+    mine = np.array([m.disp(r[0:3], r[3:6], r[6]) for r in rows])
+    assert close(mine, ref, 1e-12)
+
+
+def test_g1_is_right_handed(golden):
+    from oracle import oracle
+
+    rows, ref = golden["g1_rh_in"], golden["g1_rh_out"]
+    mine = np.array([oracle.is_right_handed(*r) for r in rows], dtype=float)
+    assert np.array_equal(mine, ref), "closed-form handedness test disagrees with the reference's SVD path"
+    assert 0.05 < ref.mean() < 0.95  # the sample exercises both outcomes
+
+
+@pytest.mark.parametrize("name", MODELS)
+def test_g2_gradients(golden, oracle_models, name):
+    m = oracle_models[name]
+    rows, ref = golden["g2_%s_in" % name], golden["g2_%s_out" % name]
+    mine = np.array([m.grad(r[0:3], r[3:6], r[6], r[7]) for r in rows])
+    assert close(mine, ref, 1e-12)
+
+
+@pytest.mark.parametrize("name", MODELS)
+def test_g3_rk_steps(golden, oracle_models, name):
+    m = oracle_models[name]
+    rows, ref = golden["g3_%s_in" % name], golden["g3_%s_out" % name]
+    mine = np.array([m.step(r[0:7], r[7], r[8]) for r in rows])
+    assert close(mine, ref, 1e-11)
+
+
+G4 = [("g4_ngo_fixed", "ngo", "g4_rays"), ("g4_ngo_adaptive", "ngo", "g4_rays"),
+      ("g4_ngoducts_adaptive", "ngoducts", "g4_rays"), ("g4_interp_fixed", "interp", "g4_rays"),
+      ("g4_interp_adaptive", "interp", "g4_rays"), ("g4_ngo_fieldaligned", "ngo", "g4_fa_rays"),
+      ("g4_ngo_launch", "ngo", "g4_launch_rays"), ("g4_interp_launch", "interp", "g4_launch_rays")]
+
+
+@pytest.mark.parametrize("tag,name,rays_key", G4)
+def test_g4_trajectories(golden, oracle_models, tag, name, rays_key):
+    m = oracle_models[name]
+    rays = golden[rays_key]
+    prm = golden[tag + "_params"]
+    ref_rows, ref_n, ref_stop = golden[tag + "_rows"], golden[tag + "_nrows"], golden[tag + "_stop"]
+    rows, nrows, stop, _ = m.trace(rays[:, 0:3], rays[:, 3:6], rays[:, 6], capacity=int(ref_rows.shape[1]),
+                                   dt0=prm[0], dtmax=prm[1], tmax=prm[2], maxerr=prm[3], minalt=prm[4],
+                                   maxsteps=int(prm[5]), root=int(prm[6]), fixedstep=int(prm[7]), del_=DELS[name])
+    if np.array_equal(nrows, ref_n):
+        assert np.array_equal(stop, ref_stop)
+        for i in range(len(nrows)):
+            assert close(rows[i, :nrows[i]], ref_rows[i, :nrows[i]], 1e-9), "ray %d" % i
+    else:
+        # only reachable with a host libm that differs from the one the goldens were made with: the
+        # trajectories are chaotic at rounding level (SURVEY A-9), so fall back to the early rows
+        assert np.mean(stop == ref_stop) >= 0.9
+        for i in range(len(nrows)):
+            k = min(3, nrows[i], ref_n[i])
+            assert close(rows[i, :k, 1:4], ref_rows[i, :k, 1:4], 1e-6)
+
+
+def test_first_attempt_policy_switch(oracle_models, golden):
+    """SURVEY A-1: flang accepts the first adaptive step without growth; the k-only policy may grow dt."""
+    m = oracle_models["ngo"]
+    rays = golden["g4_rays"]
+    kw = dict(dt0=1e-3, dtmax=0.1, tmax=0.01, maxerr=5e-4, fixedstep=0, del_=1e-4, maxsteps=50)
+    r0, n0, _, _ = m.trace(rays[:, :3], rays[:, 3:6], rays[:, 6], capacity=50, first_attempt_policy=0, **kw)
+    r1, n1, _, _ = m.trace(rays[:, :3], rays[:, 3:6], rays[:, 6], capacity=50, first_attempt_policy=1, **kw)
+    assert np.allclose(r0[:, 1, 0], 1e-3) and np.allclose(r0[:, 2, 0], 2e-3)  # 0, dt0, 2 dt0, ...
+    assert np.allclose(r1[:, 1, 0], 1e-3)
+    assert np.any(r1[:, 2, 0] > 2e-3 + 1e-9)  # dt grown to 1.25 dt0 right after step 1
