@@ -184,7 +184,7 @@ template <class M, bool FIXED, bool USE_LDS>
 __global__ __launch_bounds__(64) void trace_kernel(const M *__restrict__ mp, const Common *__restrict__ cp, TraceArgs a) {
   const M &m = *mp;
   const Common &cm = *cp;
-  __shared__ double tile[USE_LDS ? TILE_DOUBLES : 1];
+  __shared__ __attribute__((aligned(16))) double tile[USE_LDS ? TILE_DOUBLES : 2];
   double *lds = tile;
   const TraceParams &P = a.p;
   const int lane = threadIdx.x;
@@ -461,7 +461,7 @@ template <class M, bool USE_LDS>
 __global__ __launch_bounds__(64) void params_kernel(const M *__restrict__ mp, const Common *__restrict__ cp, long long n, const double *x, double *out) {
   const M &m = *mp;
   const Common &cm = *cp;
-  __shared__ double tile[USE_LDS ? TILE_DOUBLES : 1];
+  __shared__ __attribute__((aligned(16))) double tile[USE_LDS ? TILE_DOUBLES : 2];
   long long i = (long long)blockIdx.x * WAVE + threadIdx.x;
   long long j = i < n ? i : n - 1;
   double p[1][3] = {{x[3 * j], x[3 * j + 1], x[3 * j + 2]}};
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(64) void dispersion_kernel(const M *__restrict__ mp
                                                         const double *k, const double *w, double *out) {
   const M &m = *mp;
   const Common &cm = *cp;
-  __shared__ double tile[USE_LDS ? TILE_DOUBLES : 1];
+  __shared__ __attribute__((aligned(16))) double tile[USE_LDS ? TILE_DOUBLES : 2];
   long long i = (long long)blockIdx.x * WAVE + threadIdx.x;
   long long j = i < n ? i : n - 1;
   double p[1][3] = {{x[3 * j], x[3 * j + 1], x[3 * j + 2]}};
@@ -522,7 +522,7 @@ __global__ __launch_bounds__(64) void gradients_kernel(const M *__restrict__ mp,
                                                        double *out) {
   const M &m = *mp;
   const Common &cm = *cp;
-  __shared__ double tile[USE_LDS ? TILE_DOUBLES : 1];
+  __shared__ __attribute__((aligned(16))) double tile[USE_LDS ? TILE_DOUBLES : 2];
   long long i = (long long)blockIdx.x * WAVE + threadIdx.x;
   long long j = i < n ? i : n - 1;
   double st[6] = {x[3 * j], x[3 * j + 1], x[3 * j + 2], k[3 * j], k[3 * j + 1], k[3 * j + 2]};
@@ -559,7 +559,7 @@ __global__ __launch_bounds__(64) void rkstep_kernel(const M *__restrict__ mp, co
                                                     const double *dtv, double del, double *out) {
   const M &m = *mp;
   const Common &cm = *cp;
-  __shared__ double tile[USE_LDS ? TILE_DOUBLES : 1];
+  __shared__ __attribute__((aligned(16))) double tile[USE_LDS ? TILE_DOUBLES : 2];
   long long i = (long long)blockIdx.x * WAVE + threadIdx.x;
   long long j = i < n ? i : n - 1;
   double st[6];

@@ -10,8 +10,7 @@
 namespace srt {
 
 constexpr int WAVE = 64;
-constexpr int TILE_STRIDE = 65;                 // doubles per lane row in LDS (64 + 1 pad: conflict-free b64 reads)
-constexpr int TILE_DOUBLES = WAVE * TILE_STRIDE; // 33,280 B per wave
+constexpr int TILE_DOUBLES = WAVE * 64; // one species' coefficients for all 64 lanes: 32 KiB per wave
 
 // =============================================================================================
 // modelnum = 1: Ngo diffusive-equilibrium model.
@@ -182,8 +181,9 @@ struct Axis {
     if (!(f >= 0.0)) g = 0;
     else if (f >= (double)n) g = n;
     else g = (int)f + 1;
-    while (g < n && node(g) <= xi) ++g;
-    while (g > 0 && node(g - 1) > xi) --g;
+    // the quotient is within one node of the exact answer: one correction each way, no loops
+    g += (g < n && node(g) <= xi) ? 1 : 0;
+    g -= (g > 0 && node(g - 1) > xi) ? 1 : 0;
     xl = (g >= 1 && g < n) ? (xi - node(g - 1)) / del : 0.0;
     return g;
   }
@@ -200,8 +200,9 @@ struct InterpModel {
 
   // tricubic_eval with derx=dery=derz=0 (libtricubic.f95:658-695) for NP points that share one cell:
   // nested Horner, coefficient-outer / point-inner so each coefficient is read once.
-  template <int NP, class Load>
-  __device__ __forceinline__ static void eval(Load a, const double (&x)[NP], const double (&y)[NP],
+  // chunk(q) returns coefficients (2q, 2q+1).
+  template <int NP, class Chunk>
+  __device__ __forceinline__ static void eval(Chunk chunk, const double (&x)[NP], const double (&y)[NP],
                                               const double (&z)[NP], double (&out)[NP]) {
     double vz[NP];
 #pragma unroll
@@ -213,11 +214,11 @@ struct InterpModel {
       for (int i = 0; i < NP; ++i) vy[i] = 0.0;
 #pragma unroll
       for (int j = 3; j >= 0; --j) {
-        int b = 4 * j + 16 * k;
-        double a0 = a(b), a1 = a(b + 1), a2 = a(b + 2), a3 = a(b + 3);
+        const int q = 2 * j + 8 * k;
+        double2 lo = chunk(q), hi = chunk(q + 1);
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
-          double vx = fma(fma(fma(a3, x[i], a2), x[i], a1), x[i], a0);
+          double vx = fma(fma(fma(hi.y, x[i], hi.x), x[i], lo.y), x[i], lo.x);
           vy[i] = fma(vy[i], y[i], vx);
         }
       }
@@ -234,9 +235,9 @@ struct InterpModel {
     int ci = ax.locate(x, xl), cj = ay.locate(y, yl), ck = az.locate(z, zl);
     const double *base = coef + (size_t)cell_id(ci, cj, ck) * (size_t)(nspec * 64);
     for (int s = 0; s < nspec; ++s) {
-      const double *a = base + s * 64;
+      const double2 *a = reinterpret_cast<const double2 *>(base + s * 64);
       double x1[1] = {xl}, y1[1] = {yl}, z1[1] = {zl}, o1[1];
-      eval<1>([&](int i) { return a[i]; }, x1, y1, z1, o1);
+      eval<1>([&](int q) { return a[q]; }, x1, y1, z1, o1);
       lnN[s] = o1[0];
     }
   }
@@ -259,18 +260,27 @@ struct InterpModel {
     }
     const int cell = cell_id(ci, cj, ck);
     double acc[NP][4];
+    // LDS tile: row j (512 B) = lane j's 64 coefficients of one species as 32 chunks of 16 B, chunk q stored at
+    // physical chunk (q + j) & 31 so that the 16-lane groups of ds_read_b128 hit 16 different bank slots.
+    // Filled by LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B = two rows per instruction, no VGPR staging,
+    // all 32 instructions of a species in flight together); the rotation is applied on the source address.
+    const int half = lane >> 5, pchunk = lane & 31;
+    const double2 *mine = reinterpret_cast<const double2 *>(lds) + lane * 32;
     for (int s = 0; s < nspec; ++s) {
       __syncthreads(); // previous readers of the tile are done (block == one wave)
 #pragma unroll 8
-      for (int j = 0; j < WAVE; ++j) {
-        int cj_ = __builtin_amdgcn_readlane(cell, j); // wave-uniform -> scalar address
-        const double *src = coef + ((size_t)cj_ * (size_t)nspec + (size_t)s) * 64;
-        lds[j * TILE_STRIDE + lane] = src[lane]; // 512 B contiguous per instruction
+      for (int t = 0; t < 32; ++t) {
+        int c0 = __builtin_amdgcn_readlane(cell, 2 * t), c1 = __builtin_amdgcn_readlane(cell, 2 * t + 1);
+        int cj_ = half ? c1 : c0;
+        int q = (pchunk - (2 * t + half)) & 31;
+        const double *src = coef + ((size_t)cj_ * (size_t)nspec + (size_t)s) * 64 + 2 * q;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)(lds + t * 128), 16, 0, 0);
       }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      const double *mine = lds + lane * TILE_STRIDE;
       double o[NP];
-      eval<NP>([&](int c) { return mine[c]; }, xl, yl, zl, o);
+      eval<NP>([&](int q) { return mine[(q + lane) & 31]; }, xl, yl, zl, o);
 #pragma unroll
       for (int i = 0; i < NP; ++i) acc[i][s] = o[i];
     }
