@@ -234,11 +234,14 @@ struct InterpModel {
     double xl, yl, zl;
     int ci = ax.locate(x, xl), cj = ay.locate(y, yl), ck = az.locate(z, zl);
     const double *base = coef + (size_t)cell_id(ci, cj, ck) * (size_t)(nspec * 64);
-    for (int s = 0; s < nspec; ++s) {
-      const double2 *a = reinterpret_cast<const double2 *>(base + s * 64);
-      double x1[1] = {xl}, y1[1] = {yl}, z1[1] = {zl}, o1[1];
-      eval<1>([&](int q) { return a[q]; }, x1, y1, z1, o1);
-      lnN[s] = o1[0];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      if (s < nspec) {
+        const double2 *a = reinterpret_cast<const double2 *>(base + s * 64);
+        double x1[1] = {xl}, y1[1] = {yl}, z1[1] = {zl}, o1[1];
+        eval<1>([&](int q) { return a[q]; }, x1, y1, z1, o1);
+        lnN[s] = o1[0];
+      }
     }
   }
 
@@ -260,6 +263,10 @@ struct InterpModel {
     }
     const int cell = cell_id(ci, cj, ck);
     double acc[NP][4];
+#pragma unroll
+    for (int i = 0; i < NP; ++i)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[i][k] = 0.0;
     // LDS tile: row j (512 B) = lane j's 64 coefficients of one species as 32 chunks of 16 B, chunk q stored at
     // physical chunk (q + j) & 31 so that the 16-lane groups of ds_read_b128 hit 16 different bank slots.
     // Filled by LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B = two rows per instruction, no VGPR staging,
@@ -281,16 +288,20 @@ struct InterpModel {
       __syncthreads();
       double o[NP];
       eval<NP>([&](int q) { return mine[(q + lane) & 31]; }, xl, yl, zl, o);
+      // s is a run-time loop index: select statically so that acc stays in registers (no scratch)
 #pragma unroll
-      for (int i = 0; i < NP; ++i) acc[i][s] = o[i];
+      for (int i = 0; i < NP; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[i][k] = (k == s) ? o[i] : acc[i][k];
     }
     if (__any(strag != 0)) {
 #pragma unroll
       for (int i = 1; i < NP; ++i)
         if (strag & (1u << i)) {
-          double t[4];
+          double t[4] = {0.0, 0.0, 0.0, 0.0};
           point_direct(p[i][0], p[i][1], p[i][2], t);
-          for (int s = 0; s < nspec; ++s) acc[i][s] = t[s];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) acc[i][k] = t[k];
         }
     }
 #pragma unroll
