@@ -27,14 +27,10 @@ struct TraceArgs {
   TraceParams p;
 };
 
-// raytracer_evalrhs (raytracer.f95:282-314) for the state (x[0..2] position, x[3..5] wave vector).
-// 7 distinct plasma evaluations (centre + 6 stencil points; the reference evaluates the centre twice),
-// 3 + 2 + 6 Stix evaluations, 14 dispersion-function evaluations.
-template <class M>
-__device__ __forceinline__ void evalrhs(const M &m, const Common &cm, const double x[6], double w, double del,
-                                        double rhs[6], double *lds) {
-  double p[7][3];
-  double d[3];
+// Stencil of raytracer_evalrhs: centre + the six points x +- d e_c of dispersion_relation_dFdx
+// (raytracer.f95:239-262).  p[0] centre, p[1+2c] = x + d_c e_c, p[2+2c] = x - d_c e_c.
+template <int NP>
+__device__ __forceinline__ void stencil_points(const double x[3], double del, double (&p)[NP][3], double d[3]) {
 #pragma unroll
   for (int c = 0; c < 3; ++c) d[c] = fd_step(del, x[c]);
 #pragma unroll
@@ -48,19 +44,23 @@ __device__ __forceinline__ void evalrhs(const M &m, const Common &cm, const doub
     p[1 + 2 * c][c] = x[c] + d[c];
     p[2 + 2 * c][c] = x[c] - d[c];
   }
-  double Ns[7][4];
-  m.template density<7>(p, Ns, lds);
+}
 
-  double B[3];
+// raytracer_evalrhs (raytracer.f95:282-314) given the densities at the 7 stencil points: 7 dipole-field
+// evaluations, 3 + 6 Stix evaluations, 14 dispersion-function evaluations.  Also returns dF/dk and dF/dw
+// at the centre (the group-velocity terms of raytracer.f95:916-919 are the same numbers).
+template <int NP>
+__device__ __forceinline__ void rhs_from_plasma(const Common &cm, const double x[3], const double k[3], double w,
+                                                const double d[3], const double (&p)[NP][3],
+                                                const double (&Ns)[NP][4], double rhs[6], double dk[3], double &dw,
+                                                double B[3]) {
   bfield(cm.fld, x[0], x[1], x[2], B);
   double B2 = B[0] * B[0] + B[1] * B[1] + B[2] * B[2];
   double Bmag = sqrt(B2);
-  const double *k = x + 3;
   Stix st0 = stix_parameters(cm.sp, w, Ns[0], Bmag);
   double cw = cm.C / w;
-  double dk[3];
   dFdk(st0, k, cw, B, B2, dk);
-  double dw = dFdw(cm.sp, k, w, cm.C, Ns[0], B, B2, Bmag);
+  dw = dFdw(cm.sp, k, w, cm.C, Ns[0], B, B2, Bmag);
   double n[3] = {k[0] * cw, k[1] * cw, k[2] * cw};
   double dx[3];
 #pragma unroll
@@ -85,6 +85,15 @@ __device__ __forceinline__ void evalrhs(const M &m, const Common &cm, const doub
   }
 }
 
+template <class M>
+__device__ __forceinline__ void evalrhs(const M &m, const Common &cm, const double x[6], double w, double del,
+                                        double rhs[6], double *lds) {
+  double p[7][3], d[3], Ns[7][4], dk[3], dw, B[3];
+  stencil_points<7>(x, del, p, d);
+  m.template density<7>(p, Ns, lds);
+  rhs_from_plasma<7>(cm, x, x + 3, w, d, p, Ns, rhs, dk, dw, B);
+}
+
 // Explicit RK stage loop shared by rk4 (raytracer.f95:504-532) and rk45 (:534-596).
 // Stage vectors live in registers with static indices; the stage loop is not unrolled so that a
 // single copy of evalrhs sits in the instruction cache.
@@ -103,15 +112,22 @@ __constant__ Tableau TAB_RK4 = {{{0, 0, 0, 0, 0}, {0.5, 0, 0, 0, 0}, {0, 0.5, 0,
                                  {0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}},
                                 4};
 
+// r1 = evalrhs at x when the caller already has it (first stage; it does not depend on dt, so it is carried
+// from the previous accepted step and across rejected attempts), else nullptr.
 template <class M>
 __device__ __forceinline__ void rk_stages(const M &m, const Common &cm, const Tableau &tab, const double x[6],
-                                          double w, double del, double dt, double (&ks)[6][6], double *lds) {
+                                          double w, double del, double dt, double (&ks)[6][6], double *lds,
+                                          const double *r1 = nullptr) {
 #pragma unroll
   for (int j = 0; j < 6; ++j)
 #pragma unroll
     for (int c = 0; c < 6; ++c) ks[j][c] = 0.0;
+  if (r1) {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) ks[0][c] = dt * r1[c];
+  }
 #pragma unroll 1
-  for (int s = 0; s < tab.stages; ++s) {
+  for (int s = (r1 ? 1 : 0); s < tab.stages; ++s) {
     double tmp[6];
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
@@ -197,6 +213,7 @@ __global__ __launch_bounds__(64) void trace_kernel(const M *__restrict__ mp, con
   double x[6] = {2.0 * R_E, 0.0, 0.5 * R_E, 1e-3, 0.0, 1e-4}; // benign state for lanes without a ray
   double w = 2.0e4, t = 0.0, dt = P.dt0, w0 = w;
   double vg[3] = {0, 0, 0};
+  double r1[6] = {0, 0, 0, 0, 0, 0}; // evalrhs at the current state (first RK stage), carried across attempts
   double dirv[3] = {0, 0, 0};
   int nstep = 1, lastrefinedown = 0;
   bool first_attempt = true;
@@ -243,32 +260,29 @@ __global__ __launch_bounds__(64) void trace_kernel(const M *__restrict__ mp, con
       }
       if ((long long)base + nfree >= a.nrays) queue_empty = true;
     }
-    // ---- C. initialise newly claimed rays (:661-742); whole wave takes the branch together
+    // ---- C. initialise newly claimed rays (:661-742); whole wave takes the branch together.
+    // One staging serves the launch point AND the stencil of the first RK stage.
     if (__any(needinit)) {
-      double p1[1][3] = {{x[0], x[1], x[2]}};
-      double N1[1][4];
-      m.template density<1>(p1, N1, lds);
-      PointState ps;
-#pragma unroll
-      for (int s = 0; s < 4; ++s) ps.Ns[s] = N1[0][s];
-      bfield(cm.fld, x[0], x[1], x[2], ps.B);
-      ps.B2 = ps.B[0] * ps.B[0] + ps.B[1] * ps.B[1] + ps.B[2] * ps.B[2];
-      ps.Bmag = sqrt(ps.B2);
+      double p7[7][3], d7[3], N7[7][4];
+      stencil_points<7>(x, P.del, p7, d7);
+      m.template density<7>(p7, N7, lds);
       if (needinit) {
+        double B0[3];
+        bfield(cm.fld, x[0], x[1], x[2], B0);
         double dir[3] = {dirv[0], dirv[1], dirv[2]};
         if (dir[0] == 0.0 && dir[1] == 0.0 && dir[2] == 0.0) {
           // field-aligned start: B/|B| with the radial component made positive (:661-674)
           double rr = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
           double er[3] = {x[0] / rr, x[1] / rr, x[2] / rr};
-          double br = ps.B[0] * er[0] + ps.B[1] * er[1] + ps.B[2] * er[2];
+          double br = B0[0] * er[0] + B0[1] * er[1] + B0[2] * er[2];
           double adj = fabs(br) - br; // flip the radial part when negative
 #pragma unroll
-          for (int c = 0; c < 3; ++c) dir[c] = ps.B[c] + adj * er[c];
+          for (int c = 0; c < 3; ++c) dir[c] = B0[c] + adj * er[c];
           double nb = sqrt(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
 #pragma unroll
           for (int c = 0; c < 3; ++c) dir[c] /= nb;
         }
-        Roots rt = solve_dispersion(cm, dir, w0, ps.Ns, ps.B);
+        Roots rt = solve_dispersion(cm, dir, w0, N7[0], B0);
         double kre = (P.root == 1) ? rt.k1re : rt.k2re;
 #pragma unroll
         for (int c = 0; c < 3; ++c) x[3 + c] = kre * dir[c]; // real(k0mag*dir0)
@@ -278,9 +292,12 @@ __global__ __launch_bounds__(64) void trace_kernel(const M *__restrict__ mp, con
         lastrefinedown = 0;
         nstep = 1;
         first_attempt = true;
-        // row 0 (:700-742)
+        // first-stage right-hand side + the group-velocity terms of row 0 (:700-742)
         double dk[3], dw;
-        group_terms(cm, ps, x + 3, w, dk, dw);
+        PointState ps;
+        rhs_from_plasma<7>(cm, x, x + 3, w, d7, p7, N7, r1, dk, dw, ps.B);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) ps.Ns[s] = N7[0][s];
         double cw = cm.C / w;
         double n[3] = {x[3] * cw, x[4] * cw, x[5] * cw};
         double nn = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
@@ -307,28 +324,37 @@ __global__ __launch_bounds__(64) void trace_kernel(const M *__restrict__ mp, con
       continue;
     }
 
-    // ---- E. one attempt for every lane (:770-817)
+    // ---- E. one attempt for every lane (:770-817).  Stage 1 = r1 (carried); stages 2.. are evaluated here.
     acc_attempts += active ? 1ull : 0ull;
-    double ks[6][6];
-    rk_stages(m, cm, tab, x, w, P.del, dt, ks, lds);
     double est1[6], est2[6];
+    {
+      double ks[6][6];
+      rk_stages(m, cm, tab, x, w, P.del, dt, ks, lds, r1);
+      if (FIXED) {
+        rk4_combine(x, ks, est2);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) est1[c] = est2[c];
+      } else {
+        rk45_combine(x, ks, est1, est2);
+      }
+    }
     bool reject = false;
     const double dtincr = dt;
-    if (FIXED) {
-      rk4_combine(x, ks, est2);
-#pragma unroll
-      for (int c = 0; c < 6; ++c) est1[c] = est2[c];
-    } else {
-      rk45_combine(x, ks, est1, est2);
+    // One staging for everything evaluated at the step's end points: the plasma at est2 (error term, root
+    // re-projection, output row -- the reference evaluates it 4 times), its 6-point stencil (= first RK
+    // stage of the NEXT attempt), and the plasma at est1 (error term, adaptive only).
+    constexpr int NPOST = FIXED ? 7 : 8;
+    double pp[NPOST][3], dpost[3], NP_[NPOST][4];
+    stencil_points<NPOST>(est2, P.del, pp, dpost);
+    if (!FIXED) {
+      pp[NPOST - 1][0] = est1[0];
+      pp[NPOST - 1][1] = est1[1];
+      pp[NPOST - 1][2] = est1[2];
     }
-    // plasma state at est1 and est2 positions: one tile staging serves both; the est2 state also
-    // serves the root re-projection and the output row (the reference evaluates it 4 times)
-    double p2[2][3] = {{est2[0], est2[1], est2[2]}, {est1[0], est1[1], est1[2]}};
-    double N2[2][4];
-    m.template density<2>(p2, N2, lds);
+    m.template density<NPOST>(pp, NP_, lds);
     PointState ps2;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) ps2.Ns[s] = N2[0][s];
+    for (int s = 0; s < 4; ++s) ps2.Ns[s] = NP_[0][s];
     bfield(cm.fld, est2[0], est2[1], est2[2], ps2.B);
     ps2.B2 = ps2.B[0] * ps2.B[0] + ps2.B[1] * ps2.B[1] + ps2.B[2] * ps2.B[2];
     ps2.Bmag = sqrt(ps2.B2);
@@ -348,7 +374,7 @@ __global__ __launch_bounds__(64) void trace_kernel(const M *__restrict__ mp, con
       } else {
         PointState ps1;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) ps1.Ns[s] = N2[1][s];
+        for (int s = 0; s < 4; ++s) ps1.Ns[s] = NP_[NPOST - 1][s];
         bfield(cm.fld, est1[0], est1[1], est1[2], ps1.B);
         ps1.B2 = ps1.B[0] * ps1.B[0] + ps1.B[1] * ps1.B[1] + ps1.B[2] * ps1.B[2];
         ps1.Bmag = sqrt(ps1.B2);
@@ -389,6 +415,9 @@ __global__ __launch_bounds__(64) void trace_kernel(const M *__restrict__ mp, con
       double im = kmim * u;
       imsum += im * im;
     }
+    // first-stage right-hand side at the would-be new state (also yields its group-velocity terms)
+    double rn[6], dk[3], dw, Bn[3];
+    rhs_from_plasma<NPOST>(cm, est2, knew, w, dpost, pp, NP_, rn, dk, dw, Bn);
     if (active && !reject) {
       first_attempt = false; // w = est2(7) is assigned from here on (:821)
       if (imsum > 0.0) {
@@ -409,6 +438,8 @@ __global__ __launch_bounds__(64) void trace_kernel(const M *__restrict__ mp, con
           x[c] = est2[c];
           x[3 + c] = knew[c];
         }
+#pragma unroll
+        for (int c = 0; c < 6; ++c) r1[c] = rn[c];
         lastrefinedown = 0;
         t = t + dtincr;
         nstep = nstep + 1;
@@ -422,8 +453,6 @@ __global__ __launch_bounds__(64) void trace_kernel(const M *__restrict__ mp, con
           acc_steps += (unsigned long long)(nstep - 2);
           active = false;
         }
-        double dk[3], dw;
-        group_terms(cm, ps2, x + 3, w, dk, dw);
         double cw = cm.C / w;
         double n[3] = {x[3] * cw, x[4] * cw, x[5] * cw};
         double nn = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];

@@ -60,16 +60,30 @@ def test_fixed_step_trajectories(golden, gpu_models, oracle_models, name, tag, r
         assert np.allclose(rows[:, r, 0], ref_rows[:, r, 0], rtol=1e-12)  # same time grid
 
 
+C_LIGHT = 299792458.0
+
+
+def hermite(tt, t, y, v):
+    """Cubic Hermite resampling of a trajectory (positions y, velocities v at knots t) at times tt."""
+    idx = np.clip(np.searchsorted(t, tt, side="right") - 1, 0, len(t) - 2)
+    h = t[idx + 1] - t[idx]
+    u = (tt - t[idx]) / h
+    h00, h10, h01, h11 = 2 * u**3 - 3 * u**2 + 1, u**3 - 2 * u**2 + u, -2 * u**3 + 3 * u**2, u**3 - u**2
+    return (h00[:, None] * y[idx] + (h10 * h)[:, None] * v[idx] + h01[:, None] * y[idx + 1] + (h11 * h)[:, None] * v[idx + 1])
+
+
 def curve_distance(rows_a, n_a, rows_b, n_b, tmax):
-    """max over rays of the relative distance between the two position curves on a common time grid."""
+    """max over rays of the relative distance between the two position curves on a common time grid.
+    Adaptive runs place their knots differently, so both curves are resampled with cubic Hermite
+    interpolation using the group velocity (vgrel * c) the rows carry."""
     worst = 0.0
     for i in range(rows_a.shape[0]):
         ta, tb = rows_a[i, :n_a[i], 0], rows_b[i, :n_b[i], 0]
         if len(ta) < 3 or len(tb) < 3:
             continue
         tt = np.linspace(0, min(ta[-1], tb[-1], tmax), 20)
-        pa = np.stack([np.interp(tt, ta, rows_a[i, :n_a[i], 1 + c]) for c in range(3)], axis=1)
-        pb = np.stack([np.interp(tt, tb, rows_b[i, :n_b[i], 1 + c]) for c in range(3)], axis=1)
+        pa = hermite(tt, ta, rows_a[i, :n_a[i], 1:4], rows_a[i, :n_a[i], 7:10] * C_LIGHT)
+        pb = hermite(tt, tb, rows_b[i, :n_b[i], 1:4], rows_b[i, :n_b[i], 7:10] * C_LIGHT)
         worst = max(worst, float(vrel(pa, pb).max()))
     return worst
 
