@@ -54,7 +54,29 @@ def build(force=False, verbose=False):
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+    build_fortran(force, verbose)
     return LIB
+
+
+FDRV = os.path.join(BINDIR, "srt_fortran_driver")
+
+
+def build_fortran(force=False, verbose=False):
+    """The Fortran-callable shim + its example driver (needs flang; skipped quietly when absent)."""
+    fc = shutil.which("flang") or shutil.which("amdflang")
+    fdir = os.path.join(PKG, "fortran")
+    srcs = [os.path.join(fdir, "srt_bindc.f90"), os.path.join(fdir, "srt_fortran_driver.f90")]
+    if fc is None or not all(os.path.exists(s) for s in srcs):
+        return None
+    if force or _stale(FDRV, srcs + [LIB]):
+        moddir = os.path.join(PKG, "lib", "fmod")
+        os.makedirs(moddir, exist_ok=True)
+        cmd = [fc, "-O2", "-module-dir", moddir, "-o", FDRV] + srcs + ["-L" + LIBDIR, "-lsrt_hip",
+                                                                    "-Wl,-rpath,$ORIGIN/../lib"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return FDRV
 
 
 if __name__ == "__main__":

@@ -1,0 +1,67 @@
+"""GPU (-m gpu): the raytracer-compatible CLI and the Fortran-callable shim reproduce BASELINE config[0]
+(16 rays, Ngo + dipole B, fixed RK4) -- the reference's own CPU-runnable case -- in the reference's .ray format."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_DIR, ROOT, vrel
+from stanford_raytracer_amd import workloads as wl
+
+pytestmark = pytest.mark.gpu
+BIN = os.path.join(ROOT, "stanford_raytracer_amd", "bin")
+
+
+def parse_ray_file(path):
+    rows = []
+    for line in open(path):
+        assert len(line.rstrip("\n")) == 10 + 10 + 17 * 24 + 10 + 16 * 24
+        head = [int(line[0:10]), int(line[10:20])]
+        vals = [float(line[20 + 24 * i:44 + 24 * i]) for i in range(17)]
+        nspec = int(line[428:438])
+        tail = [float(line[438 + 24 * i:462 + 24 * i]) for i in range(16)]
+        rows.append(head + vals + [nspec] + tail)
+    return np.array(rows)
+
+
+def test_cli_config1_matches_reference_ray_file(tmp_path, cfgfiles, golden):
+    rays = golden["g4_rays"]
+    rf = tmp_path / "rays.txt"
+    wl.write_rays_file(str(rf), rays[:, :3], rays[:, 3:6], rays[:, 6])
+    out = tmp_path / "out.ray"
+    cmd = [os.path.join(BIN, "raytracer"), "--outputper=25", "--dt0=0.001", "--dtmax=0.1", "--tmax=0.1", "--root=2",
+           "--fixedstep=1", "--maxerr=5e-4", "--maxsteps=2000", "--minalt=%r" % wl.MINALT,
+           "--inputraysfile=%s" % rf, "--outputfile=%s" % out, "--modelnum=1", "--ngo_configfile=%s" % cfgfiles["ngo"],
+           "--yearday=2010001", "--milliseconds_day=0", "--use_tsyganenko=0", "--use_igrf=0", "--tsyganenko_Pdyn=4"]
+    subprocess.run(cmd, check=True)
+    mine = parse_ray_file(str(out))
+    ref = parse_ray_file(os.path.join(GOLDEN_DIR, "config1_outputper25.ray"))
+    assert mine.shape == ref.shape
+    assert np.array_equal(mine[:, 0:2], ref[:, 0:2])            # raynum, stopcond
+    assert np.array_equal(mine[:, 2], ref[:, 2])                # time grid (fixed step)
+    assert np.array_equal(mine[:, 18:20], ref[:, 18:20])        # w, nspec
+    assert np.array_equal(mine[:, 20:28], ref[:, 20:28]) and np.array_equal(mine[:, 32:36], ref[:, 32:36])  # qs ms nus
+    r0 = ref[:, 2] == 0
+    assert np.array_equal(mine[r0, 3:6], ref[r0, 3:6])
+    assert vrel(mine[:, 3:6], ref[:, 3:6]).max() <= 1e-3         # row 100 of the ladder x10 (4e-5 -> 4e-4) with margin
+    assert vrel(mine[ref[:, 2] <= 0.0251, 3:6], ref[ref[:, 2] <= 0.0251, 3:6]).max() <= 1e-5
+    assert np.max(np.abs(mine[:, 28:32] - ref[:, 28:32]) / ref[:, 28:32]) <= 1e-2  # Ns along the diverging paths
+
+    # the Fortran program over the bind(C) shim writes the same file through the same library
+    fdrv = os.path.join(BIN, "srt_fortran_driver")
+    if os.path.exists(fdrv):
+        out2 = tmp_path / "out_fortran.ray"
+        subprocess.run([fdrv, cfgfiles["ngo"], str(rf), str(out2)], check=True)
+        assert out2.read_text() == out.read_text()
+
+
+def test_cli_rejects_out_of_scope_requests(tmp_path, cfgfiles):
+    rf = tmp_path / "rays.txt"
+    rf.write_text("7e6 0 0 1 0 0 1e4\n")
+    base = [os.path.join(BIN, "raytracer"), "--dt0=1e-3", "--tmax=0.01", "--root=2", "--fixedstep=1", "--maxsteps=10",
+            "--minalt=6.4712e6", "--inputraysfile=%s" % rf, "--outputfile=%s" % (tmp_path / "o.ray"), "--yearday=2010001",
+            "--milliseconds_day=0", "--ngo_configfile=%s" % cfgfiles["ngo"]]
+    assert subprocess.run(base + ["--modelnum=1", "--use_igrf=1"]).returncode == 2
+    assert subprocess.run(base + ["--modelnum=2"]).returncode == 2
+    assert subprocess.run(base + ["--modelnum=1"]).returncode == 0
