@@ -1191,8 +1191,16 @@ static void *batch_worker(void *arg) {
   batch_job *j = (batch_job *)arg;
   so_model *m = j->m;
   so_model local;
+  struct so_scattered lsc;
   if (m->kind == 1) { /* Ngo model has per-call scratch state: give each thread its own copy */
     local = *m;
+    m = &local;
+  } else if (m->kind == 4) { /* scattered model: per-thread neighbour scratch buffer */
+    local = *m;
+    lsc = *m->sc;
+    lsc.found = NULL;
+    lsc.cap = 0;
+    local.sc = &lsc;
     m = &local;
   }
   j->steps = 0;
@@ -1205,6 +1213,7 @@ static void *batch_worker(void *arg) {
     j->stopcond[r] = sc;
     j->steps += nt - 1;
   }
+  if (m->kind == 4) free(lsc.found);
   return NULL;
 }
 long so_trace_batch(so_model *m, const so_params *p, long nrays, const double *pos0,

@@ -25,7 +25,25 @@ typedef struct {
   double *arr[8]; /* F, dfdx, dfdy, dfdz, d2fdxdy, d2fdxdz, d2fdydz, d3fdxdydz */
 } so_grid;
 
-struct so_scattered;
+#ifndef SO_MAXSPEC
+#define SO_MAXSPEC 4
+#endif
+typedef struct {
+  double p[3];
+  double val[SO_MAXSPEC + 1]; /* ln N_s ..., then distance to the nearest other sample */
+  int dim, left, right;
+} kdnode;
+
+struct so_scattered {
+  kdnode *nodes;
+  int n, root, nspec;
+  double qs[4], ms[4];
+  double window_scale, local_window_scale, maxnearest;
+  int order, exact;
+  /* scratch for searches */
+  int *found, cap;
+};
+
 
 struct so_model {
   int kind, nspec;

@@ -26,6 +26,17 @@ def grid16():
 
 
 @pytest.fixture(scope="session")
+def pointsfile(tmp_path_factory):
+    """Model-4 sample file written from the committed fixture (the same bytes the goldens were made with)."""
+    from stanford_raytracer_amd import workloads as wl
+
+    g = np.load(os.path.join(GOLDEN_DIR, "points5500.npz"))
+    path = str(tmp_path_factory.mktemp("pts") / "points.txt")
+    wl.write_points_file(path, g["pts"], g["lnN"], g["bounds"], g["qs"], g["ms"])
+    return path
+
+
+@pytest.fixture(scope="session")
 def cfgfiles(tmp_path_factory):
     from stanford_raytracer_amd import workloads as wl
 
@@ -57,7 +68,7 @@ def gpu_models(cfgfiles, grid16):
             "interp": api.Model.interp(F, b, qs, ms)}
 
 
-DELS = {"ngo": 1e-4, "ngoducts": 1e-4, "interp": 1e-6}
+DELS = {"ngo": 1e-4, "ngoducts": 1e-4, "interp": 1e-6, "scattered": 1e-6}
 
 
 def vrel(a, b):

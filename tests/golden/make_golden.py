@@ -72,6 +72,12 @@ def main():
     gridfile = os.path.join(work, "grid16.txt")
     wl.write_grid_file(gridfile, F, bounds)
     np.savez_compressed(os.path.join(HERE, "grid16.npz"), F=F, bounds=bounds, qs=wl.QS, ms=wl.MS)
+    pts, lnN = wl.make_points(5000, 500, 7, half_width=5.0 * wl.R_E)
+    ptsfile = os.path.join(work, "points.txt")
+    pbounds = np.array([-5.0 * wl.R_E, 5.0 * wl.R_E] * 3)
+    wl.write_points_file(ptsfile, pts, lnN, pbounds)
+    np.savez_compressed(os.path.join(HERE, "points5500.npz"), pts=pts, lnN=lnN, bounds=pbounds, qs=wl.QS, ms=wl.MS)
+    scat = {"kind": 4, "file": ptsfile, "window_scale": 1.5, "order": 2, "exact": 0, "local_window_scale": 5.0}
     models = {
         "ngo": {"kind": 1, "file": cfg_pp},
         "ngoducts": {"kind": 1, "file": cfg_du},
@@ -92,6 +98,15 @@ def main():
         x = np.concatenate([pos, edge, wide]) if name == "interp" else np.concatenate([pos, wide[:20]])
         store["g0_%s_x" % name] = x
         store["g0_%s_out" % name] = refharness.run_mode("params", x, mdl)
+
+    # scattered model (modelnum 4): inside the Earth (Ns = 0 -> free-space branch), far outside the cloud
+    # (too few neighbours -> status 2 -> Ns = 1), and ordinary points; also order 1 and the exact window
+    xs_ = np.concatenate([pos[:120] * 0.9, np.array([[0.5 * wl.R_E, 0, 0], [0, 0, 0.99 * wl.R_E],
+                                                     [4.9 * wl.R_E] * 3, [6.0 * wl.R_E] * 3, [9 * wl.R_E, 0, 0]])])
+    store["g0_scattered_x"] = xs_
+    store["g0_scattered_out"] = refharness.run_mode("params", xs_, scat)
+    store["g0_scattered_o1_out"] = refharness.run_mode("params", xs_, dict(scat, order=1))
+    store["g0_scattered_exact_out"] = refharness.run_mode("params", xs_, dict(scat, exact=1, local_window_scale=2.0))
 
     # ---- G1: dispersion relation, Stix parameters, both roots; is_right_handed
     for name, mdl in models.items():
@@ -145,6 +160,8 @@ def main():
     store["g4_launch_rays"] = np.concatenate([lp, ld, lw[:, None]], axis=1)
     run_set(models["ngo"], lp, ld, lw, "g4_ngo_launch", store, fixedstep=0, tmax=0.05)
     run_set(models["interp"], lp, ld, lw, "g4_interp_launch", store, fixedstep=0, tmax=0.02, maxsteps=100)
+    run_set(scat, lp * 0.9, ld, lw, "g4_scattered_launch", store, fixedstep=0, tmax=0.01, maxsteps=60)
+    store["g4_scattered_rays"] = np.concatenate([lp * 0.9, ld, lw[:, None]], axis=1)
     # the text .ray file of config 1 (record format of raytracer_driver.f95:1197-1217)
     with open(os.path.join(work, "config1.ray")) as f:
         text = f.read()
