@@ -14,6 +14,7 @@
 #include "../../include/srt.h"
 #include "srt_host.hpp"
 #include "srt_kernels.hpp"
+#include "srt_scattered.hpp"
 #include "tricubic_matrix.h"
 
 using namespace srt;
@@ -70,6 +71,9 @@ struct srt_model {
   Common cm{};
   NgoModel ngo{};
   InterpModel interp{};
+  ScatteredModel scat{};
+  double *d_pts = nullptr;
+  int *d_cells = nullptr;
   double *d_coef = nullptr;
   void *d_model = nullptr;   // device copy of ngo / interp (kernels read it through scalar loads)
   Common *d_common = nullptr;
@@ -110,6 +114,9 @@ static int model_finish(srt_model *m) {
   } else if (m->kind == 3) {
     HIP_OK(hipMalloc(&m->d_model, sizeof(InterpModel)));
     HIP_OK(hipMemcpy(m->d_model, &m->interp, sizeof(InterpModel), hipMemcpyHostToDevice));
+  } else if (m->kind == 4) {
+    HIP_OK(hipMalloc(&m->d_model, sizeof(ScatteredModel)));
+    HIP_OK(hipMemcpy(m->d_model, &m->scat, sizeof(ScatteredModel), hipMemcpyHostToDevice));
   }
   hipDeviceProp_t p;
   HIP_OK(hipGetDeviceProperties(&p, g_device));
@@ -122,6 +129,8 @@ static int model_finish(srt_model *m) {
 extern "C" void srt_model_destroy(srt_model *m) {
   if (!m) return;
   if (m->d_coef) (void)hipFree(m->d_coef);
+  if (m->d_pts) (void)hipFree(m->d_pts);
+  if (m->d_cells) (void)hipFree(m->d_cells);
   if (m->d_model) (void)hipFree(m->d_model);
   if (m->d_common) (void)hipFree(m->d_common);
   if (m->ev0) (void)hipEventDestroy(m->ev0);
@@ -404,8 +413,51 @@ extern "C" int srt_model_create_interp_file(const char *gridfile, int yearday, i
                                  gf.have_derivs ? dptr : nullptr, yearday, msec, out);
 }
 
-extern "C" int srt_model_create_scattered_file(const char *, int, int, double, int, int, double, srt_model **) {
-  return srt_set_error(SRT_EINVAL, "scattered model (modelnum=4) is not built yet in this round");
+extern "C" int srt_model_create_scattered_file(const char *ptsfile, int yearday, int msec, double window_scale,
+                                               int order, int exact, double local_window_scale, srt_model **out) {
+  if (!ptsfile || !out) return srt_set_error(SRT_EINVAL, "null argument");
+  if (order < 0 || order > 2)
+    return srt_set_error(SRT_EINVAL, "scattered_interp_order=%d: orders 0..2 are built (order 3 needs a 20x20 system per lane)", order);
+  if (!(window_scale > 0) || !(local_window_scale > 0)) return srt_set_error(SRT_EINVAL, "window scales must be > 0");
+  int rc = ensure_init();
+  if (rc) return rc;
+  srt_host::ScatteredHost h;
+  std::string err;
+  if (!srt_host::build_scattered(ptsfile, window_scale, h, err)) return srt_set_error(SRT_EIO, "%s: %s", ptsfile, err.c_str());
+  srt_model *m = new srt_model;
+  m->kind = 4;
+  m->nspec = h.nspec;
+  hipError_t e = hipMalloc(&m->d_pts, h.pts.size() * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc(&m->d_cells, h.cell_start.size() * sizeof(int));
+  if (e == hipSuccess) e = hipMemcpy(m->d_pts, h.pts.data(), h.pts.size() * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(m->d_cells, h.cell_start.data(), h.cell_start.size() * sizeof(int), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    srt_model_destroy(m);
+    return srt_set_error(e == hipErrorOutOfMemory ? SRT_ENOMEM : SRT_EDEVICE, "scattered model upload: %s", hipGetErrorString(e));
+  }
+  m->device_bytes = (int64_t)(h.pts.size() * sizeof(double) + h.cell_start.size() * sizeof(int));
+  ScatteredModel &s = m->scat;
+  s.pts = m->d_pts;
+  s.cell_start = m->d_cells;
+  for (int k = 0; k < 3; ++k) {
+    s.origin[k] = h.origin[k];
+    s.dims[k] = h.dims[k];
+  }
+  s.inv_cell = h.inv_cell;
+  s.radius = h.radius;
+  s.lws = local_window_scale;
+  s.nspec = h.nspec;
+  s.order = order;
+  s.exact = exact;
+  s.npts = h.npts;
+  fill_common(m->cm, h.nspec, h.qs, h.ms, yearday, msec);
+  rc = model_finish(m);
+  if (rc) {
+    srt_model_destroy(m);
+    return rc;
+  }
+  *out = m;
+  return SRT_OK;
 }
 
 // ------------------------------------------------------------------------------------------ launches
@@ -440,6 +492,8 @@ extern "C" int srt_plasma_params(srt_model *m, int64_t n, const double *x, doubl
   if (dout.alloc(19 * n)) return srt_set_error(SRT_ENOMEM, "hipMalloc failed");
   if (m->kind == 1) launch_wave_blocks(params_kernel<NgoModel, false>, n, 0, (const NgoModel *)m->d_model, (const Common *)m->d_common, (long long)n, (const double *)dx.p, dout.p);
   else if (m->kind == 3) launch_wave_blocks(params_kernel<InterpModel, true>, n, 0, (const InterpModel *)m->d_model, (const Common *)m->d_common, (long long)n, (const double *)dx.p, dout.p);
+  else if (m->kind == 4)
+    launch_wave_blocks(params_kernel<ScatteredModel, false>, n, 0, (const ScatteredModel *)m->d_model, (const Common *)m->d_common, (long long)n, (const double *)dx.p, dout.p);
   else return srt_set_error(SRT_EINVAL, "model kind %d unsupported", m->kind);
   std::vector<double> h(19 * n);
   HIP_OK(hipMemcpy(h.data(), dout.p, h.size() * sizeof(double), hipMemcpyDeviceToHost));
@@ -468,6 +522,8 @@ extern "C" int srt_dispersion(srt_model *m, int64_t n, const double *x, const do
     launch_wave_blocks(dispersion_kernel<NgoModel, false>, n, 0, (const NgoModel *)m->d_model, (const Common *)m->d_common, (long long)n, (const double *)dx.p, (const double *)dk.p, (const double *)dw.p, dout.p);
   else if (m->kind == 3)
     launch_wave_blocks(dispersion_kernel<InterpModel, true>, n, 0, (const InterpModel *)m->d_model, (const Common *)m->d_common, (long long)n, (const double *)dx.p, (const double *)dk.p, (const double *)dw.p, dout.p);
+  else if (m->kind == 4)
+    launch_wave_blocks(dispersion_kernel<ScatteredModel, false>, n, 0, (const ScatteredModel *)m->d_model, (const Common *)m->d_common, (long long)n, (const double *)dx.p, (const double *)dk.p, (const double *)dw.p, dout.p);
   else return srt_set_error(SRT_EINVAL, "model kind %d unsupported", m->kind);
   HIP_OK(hipMemcpy(out, dout.p, 10 * n * sizeof(double), hipMemcpyDeviceToHost));
   return SRT_OK;
@@ -501,6 +557,8 @@ extern "C" int srt_gradients(srt_model *m, int64_t n, const double *x, const dou
     launch_wave_blocks(gradients_kernel<NgoModel, false>, n, 0, (const NgoModel *)m->d_model, (const Common *)m->d_common, (long long)n, (const double *)dx.p, (const double *)dk.p, (const double *)dw.p, del, dout.p);
   else if (m->kind == 3)
     launch_wave_blocks(gradients_kernel<InterpModel, true>, n, 0, (const InterpModel *)m->d_model, (const Common *)m->d_common, (long long)n, (const double *)dx.p, (const double *)dk.p, (const double *)dw.p, del, dout.p);
+  else if (m->kind == 4)
+    launch_wave_blocks(gradients_kernel<ScatteredModel, false>, n, 0, (const ScatteredModel *)m->d_model, (const Common *)m->d_common, (long long)n, (const double *)dx.p, (const double *)dk.p, (const double *)dw.p, del, dout.p);
   else return srt_set_error(SRT_EINVAL, "model kind %d unsupported", m->kind);
   HIP_OK(hipMemcpy(out, dout.p, 14 * n * sizeof(double), hipMemcpyDeviceToHost));
   return SRT_OK;
@@ -518,6 +576,8 @@ extern "C" int srt_rk_step(srt_model *m, int64_t n, const double *args, const do
     launch_wave_blocks(rkstep_kernel<NgoModel, false>, n, 0, (const NgoModel *)m->d_model, (const Common *)m->d_common, (long long)n, (const double *)da.p, (const double *)dd.p, del, dout.p);
   else if (m->kind == 3)
     launch_wave_blocks(rkstep_kernel<InterpModel, true>, n, 0, (const InterpModel *)m->d_model, (const Common *)m->d_common, (long long)n, (const double *)da.p, (const double *)dd.p, del, dout.p);
+  else if (m->kind == 4)
+    launch_wave_blocks(rkstep_kernel<ScatteredModel, false>, n, 0, (const ScatteredModel *)m->d_model, (const Common *)m->d_common, (long long)n, (const double *)da.p, (const double *)dd.p, del, dout.p);
   else return srt_set_error(SRT_EINVAL, "model kind %d unsupported", m->kind);
   HIP_OK(hipMemcpy(out, dout.p, 21 * n * sizeof(double), hipMemcpyDeviceToHost));
   return SRT_OK;
@@ -578,6 +638,9 @@ extern "C" int srt_trace_batch_device(srt_model *m, const srt_params *p, int64_t
   } else if (m->kind == 3) {
     if (fixed) hipLaunchKernelGGL((trace_kernel<InterpModel, true, true>), dim3((unsigned)grid), dim3(WAVE), 0, st, (const InterpModel *)m->d_model, (const Common *)m->d_common, a);
     else hipLaunchKernelGGL((trace_kernel<InterpModel, false, true>), dim3((unsigned)grid), dim3(WAVE), 0, st, (const InterpModel *)m->d_model, (const Common *)m->d_common, a);
+  } else if (m->kind == 4) {
+    if (fixed) hipLaunchKernelGGL((trace_kernel<ScatteredModel, true, false>), dim3((unsigned)grid), dim3(WAVE), 0, st, (const ScatteredModel *)m->d_model, (const Common *)m->d_common, a);
+    else hipLaunchKernelGGL((trace_kernel<ScatteredModel, false, false>), dim3((unsigned)grid), dim3(WAVE), 0, st, (const ScatteredModel *)m->d_model, (const Common *)m->d_common, a);
   } else {
     return srt_set_error(SRT_EINVAL, "model kind %d unsupported", m->kind);
   }

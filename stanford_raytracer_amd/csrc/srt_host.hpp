@@ -48,3 +48,19 @@ private:
 void format_es24(double v, char out[25]);
 
 } // namespace srt_host
+
+namespace srt_host {
+// model-4 scattered sample file (scattered_interp_dens_model_adapter.f95:85-133) prepared for the device:
+// duplicates dropped (:160-163), nearest-sample distance per sample outside the Earth (:167-203),
+// samples binned into a uniform grid with cell edge = maxnearest*window_scale and sorted by cell.
+struct ScatteredHost {
+  int nspec = 0, npts = 0;
+  double qs[4] = {0}, ms[4] = {0};
+  double maxnearest = 0, radius = 0;
+  double origin[3] = {0, 0, 0}, inv_cell = 0;
+  int dims[3] = {1, 1, 1};
+  std::vector<double> pts;       // [npts][8]
+  std::vector<int> cell_start;   // [ncells+1]
+};
+bool build_scattered(const char *path, double window_scale, ScatteredHost &out, std::string &err);
+} // namespace srt_host

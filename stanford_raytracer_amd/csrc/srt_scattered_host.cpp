@@ -1,0 +1,158 @@
+// srt_scattered_host.cpp -- host-side preparation of the scattered-sample model (no device code).
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+
+#include "srt_host.hpp"
+
+namespace srt_host {
+
+static const double R_E = 6371.2e3;
+
+namespace {
+struct Grid {
+  double origin[3], inv;
+  int dims[3];
+  std::vector<int> start, order; // CSR over cells; order = sample indices sorted by cell
+  int cell_of(const double *p, int k) const {
+    int c = (int)std::floor((p[k] - origin[k]) * inv);
+    return c < 0 ? 0 : (c >= dims[k] ? dims[k] - 1 : c);
+  }
+  size_t id(int cx, int cy, int cz) const { return ((size_t)cz * dims[1] + cy) * dims[0] + cx; }
+};
+
+void build_grid(const std::vector<double> &xyz, int n, double cell, const double lo[3], const double hi[3], Grid &g) {
+  g.inv = 1.0 / cell;
+  size_t ncell = 1;
+  for (int k = 0; k < 3; ++k) {
+    g.origin[k] = lo[k];
+    g.dims[k] = std::max(1, (int)std::floor((hi[k] - lo[k]) * g.inv) + 1);
+    ncell *= (size_t)g.dims[k];
+  }
+  g.start.assign(ncell + 1, 0);
+  std::vector<size_t> cid(n);
+  for (int i = 0; i < n; ++i) {
+    const double *p = &xyz[3 * (size_t)i];
+    cid[i] = g.id(g.cell_of(p, 0), g.cell_of(p, 1), g.cell_of(p, 2));
+    g.start[cid[i] + 1]++;
+  }
+  for (size_t c = 0; c < ncell; ++c) g.start[c + 1] += g.start[c];
+  g.order.resize(n);
+  std::vector<int> fill(g.start.begin(), g.start.end() - 1);
+  for (int i = 0; i < n; ++i) g.order[fill[cid[i]]++] = i;
+}
+} // namespace
+
+bool build_scattered(const char *path, double window_scale, ScatteredHost &out, std::string &err) {
+  ListReader r(path);
+  if (!r.ok()) {
+    err = "cannot open";
+    return false;
+  }
+  double hdr[7];
+  if (r.read(7, hdr) != 7) { err = "header (nspec + bounds) incomplete"; return false; }
+  int nspec = (int)hdr[0];
+  if (nspec < 1 || nspec > 4) { err = "nspec must be 1..4"; return false; }
+  out.nspec = nspec;
+  if (r.read(nspec, out.qs) != nspec || r.read(nspec, out.ms) != nspec) { err = "charges/masses incomplete"; return false; }
+  std::vector<double> raw;
+  double row[8];
+  while (r.read(3 + nspec, row) == 3 + nspec) raw.insert(raw.end(), row, row + 3 + nspec);
+  const int w = 3 + nspec;
+  int n0 = (int)(raw.size() / w);
+  if (n0 == 0) { err = "no samples"; return false; }
+  // drop exact duplicates (the reference ignores a sample whose position is already in the tree)
+  std::vector<int> idx(n0);
+  std::iota(idx.begin(), idx.end(), 0);
+  std::sort(idx.begin(), idx.end(), [&](int a, int b) {
+    const double *pa = &raw[(size_t)a * w], *pb = &raw[(size_t)b * w];
+    if (pa[0] != pb[0]) return pa[0] < pb[0];
+    if (pa[1] != pb[1]) return pa[1] < pb[1];
+    if (pa[2] != pb[2]) return pa[2] < pb[2];
+    return a < b;
+  });
+  std::vector<int> keep;
+  for (int j = 0; j < n0; ++j) {
+    if (j > 0) {
+      const double *pa = &raw[(size_t)idx[j - 1] * w], *pb = &raw[(size_t)idx[j] * w];
+      if (pa[0] == pb[0] && pa[1] == pb[1] && pa[2] == pb[2]) continue;
+    }
+    keep.push_back(idx[j]);
+  }
+  std::sort(keep.begin(), keep.end());
+  const int n = (int)keep.size();
+  std::vector<double> xyz(3 * (size_t)n);
+  double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+  for (int i = 0; i < n; ++i)
+    for (int k = 0; k < 3; ++k) {
+      double v = raw[(size_t)keep[i] * w + k];
+      xyz[3 * (size_t)i + k] = v;
+      lo[k] = std::min(lo[k], v);
+      hi[k] = std::max(hi[k], v);
+    }
+  // nearest other sample for every sample outside the Earth: uniform search grid with ~4 samples per cell
+  double vol = 1.0;
+  for (int k = 0; k < 3; ++k) vol *= std::max(hi[k] - lo[k], 1.0);
+  double cell = std::cbrt(vol / std::max(n, 1) * 4.0);
+  Grid g;
+  build_grid(xyz, n, cell, lo, hi, g);
+  std::vector<double> nn(n, 1.0); // placeholder 1.0 for samples inside the Earth (scattered_..adapter.f95:152)
+  double maxnearest = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const double *p = &xyz[3 * (size_t)i];
+    if (p[0] * p[0] + p[1] * p[1] + p[2] * p[2] < R_E * R_E) continue;
+    int c[3] = {g.cell_of(p, 0), g.cell_of(p, 1), g.cell_of(p, 2)};
+    double best = -1.0;
+    int maxring = std::max(g.dims[0], std::max(g.dims[1], g.dims[2]));
+    for (int ring = 1; ring <= maxring; ++ring) {
+      for (int cz = std::max(0, c[2] - ring); cz <= std::min(g.dims[2] - 1, c[2] + ring); ++cz)
+        for (int cy = std::max(0, c[1] - ring); cy <= std::min(g.dims[1] - 1, c[1] + ring); ++cy)
+          for (int cx = std::max(0, c[0] - ring); cx <= std::min(g.dims[0] - 1, c[0] + ring); ++cx) {
+            // only the shell of this ring (inner cells were scanned at smaller rings)
+            if (ring > 1 && std::abs(cx - c[0]) < ring && std::abs(cy - c[1]) < ring && std::abs(cz - c[2]) < ring) continue;
+            size_t id = g.id(cx, cy, cz);
+            for (int s = g.start[id]; s < g.start[id + 1]; ++s) {
+              int j = g.order[s];
+              if (j == i) continue;
+              const double *q = &xyz[3 * (size_t)j];
+              double d2 = (q[0] - p[0]) * (q[0] - p[0]) + (q[1] - p[1]) * (q[1] - p[1]) + (q[2] - p[2]) * (q[2] - p[2]);
+              if (best < 0 || d2 < best) best = d2;
+            }
+          }
+      // the scanned cube extends at least ring*cell beyond p in every direction: nothing closer can remain
+      if (best >= 0 && std::sqrt(best) <= (double)ring * cell) break;
+    }
+    if (best >= 0) {
+      nn[i] = std::sqrt(best);
+      maxnearest = std::max(maxnearest, nn[i]);
+    }
+  }
+  out.maxnearest = maxnearest;
+  out.radius = maxnearest * window_scale;
+  if (!(out.radius > 0)) { err = "degenerate sample set (max nearest distance is zero)"; return false; }
+  // query grid: cell edge = radius, samples sorted by cell
+  Grid q;
+  build_grid(xyz, n, out.radius, lo, hi, q);
+  out.npts = n;
+  out.inv_cell = q.inv;
+  for (int k = 0; k < 3; ++k) {
+    out.origin[k] = q.origin[k];
+    out.dims[k] = q.dims[k];
+  }
+  out.cell_start = q.start;
+  out.pts.assign((size_t)n * 8, 0.0);
+  for (int s = 0; s < n; ++s) {
+    int i = q.order[s];
+    double *dst = &out.pts[(size_t)s * 8];
+    dst[0] = xyz[3 * (size_t)i];
+    dst[1] = xyz[3 * (size_t)i + 1];
+    dst[2] = xyz[3 * (size_t)i + 2];
+    for (int k = 0; k < nspec; ++k) dst[3 + k] = raw[(size_t)keep[i] * w + 3 + k];
+    dst[7] = nn[i];
+  }
+  return true;
+}
+
+} // namespace srt_host

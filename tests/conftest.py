@@ -59,13 +59,21 @@ def oracle_models(cfgfiles, grid16):
 
 
 @pytest.fixture(scope="session")
-def gpu_models(cfgfiles, grid16):
+def gpu_models(cfgfiles, grid16, pointsfile):
     from stanford_raytracer_amd import api
 
     api.init(0)
     F, b, qs, ms = grid16
     return {"ngo": api.Model.ngo(cfgfiles["ngo"]), "ngoducts": api.Model.ngo(cfgfiles["ngoducts"]),
-            "interp": api.Model.interp(F, b, qs, ms)}
+            "interp": api.Model.interp(F, b, qs, ms), "scattered": api.Model.scattered_file(pointsfile)}
+
+
+@pytest.fixture(scope="session")
+def oracle_scattered(pointsfile):
+    from oracle import oracle
+
+    # bit 31 of perm_seed: true nearest-sample distance for the tree root too (what the HIP path stores)
+    return oracle.Model.scattered_file(pointsfile, perm_seed=2 | 0x80000000)
 
 
 DELS = {"ngo": 1e-4, "ngoducts": 1e-4, "interp": 1e-6, "scattered": 1e-6}
