@@ -33,6 +33,8 @@ ALGO_BYTES_PER_STEP = {  # algorithmic bytes per ACCEPTED ray-st
     "interp": lambda outputper: 44 * 2048 + 160 + 256.0 / outputper,
     # no table: state r/w + emitted row only
     "ngo": lambda outputper: 160 + 256.0 / outputper,
+    # scattered: data-dependent (visited samples x 64 B per lookup); reported from the neighbour statistics
+    "scattered": lambda outputper: 160 + 256.0 / outputper,
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
@@ -42,10 +44,11 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="interp256", choices=["interp256", "ngo100k"])
+    ap.add_argument("--workload", default="interp256", choices=["interp256", "ngo100k", "scattered825k"])
     ap.add_argument("--rays", type=int, default=0, help="override rays per GPU")
     ap.add_argument("--grid", type=int, default=0, help="override grid nodes per axis (interp)")
     ap.add_argument("--maxsteps", type=int, default=0)
+    ap.add_argument("--points", type=int, default=0, help="override sample count (scattered)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline sample duration (0=skip)")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--refill", type=int, default=0)
@@ -89,6 +92,21 @@ def main():
         del F
         setup_s = time.time() - t0
         wname = "%d rays/GPU, interp_dens_model on %d^3 x4 lnN grid (tricubic), dipole B, adaptive RK45" % (nrays, grid_n)
+    elif args.workload == "scattered825k":
+        kind = "scattered"
+        nrays = args.rays or 1_000_000
+        grid_n = 0
+        seed = 5
+        p = api.make_params(fixedstep=0, dt0=1e-3, dtmax=0.1, maxerr=5e-4, tmax=0.5, root=2, minalt=wl.MINALT,
+                            maxsteps=args.maxsteps or 64, outputper=8, del_=1e-6, refill_threshold=args.refill)
+        t0 = time.time()
+        npts = args.points or 825_000
+        pts, lnN = wl.make_points(int(npts * 0.97), npts - int(npts * 0.97), 5, half_width=10.0 * wl.R_E)
+        pfile = os.path.join(tempfile.mkdtemp(), "points.txt")
+        wl.write_points_file(pfile, pts, lnN, np.array([-10.0 * wl.R_E, 10.0 * wl.R_E] * 3))
+        model = api.Model.scattered_file(pfile, window_scale=1.5, order=2, exact=0, local_window_scale=5.0)
+        setup_s = time.time() - t0
+        wname = "%d rays/GPU, scattered_interp_dens_model (%d samples, order 2, window 1.5/5), dipole B, adaptive RK45" % (nrays, npts)
     else:
         kind = "ngo"
         nrays = args.rays or 100_000
@@ -223,6 +241,8 @@ def cpu_baseline(args, kind, p, wl, pos0, dir0, w0, grid_n):
         F, bounds = wl.make_grid(grid_n, half_width=10.0 * wl.R_E)
         om = oracle.Model.interp(F, bounds, wl.QS, wl.MS)
         del F
+    elif kind == "scattered":
+        return {"skipped": "scattered CPU baseline not wired into bench (see BASELINE.md: reference 0.13 k steps/s/core)"}
     else:
         cfg = os.path.join(tempfile.mkdtemp(), "newray.in")
         with open(cfg, "w") as f:
