@@ -90,7 +90,7 @@ __device__ __forceinline__ void evalrhs(const M &m, const Common &cm, const doub
                                         double rhs[6], double *lds) {
   double p[7][3], d[3], Ns[7][4], dk[3], dw, B[3];
   stencil_points<7>(x, del, p, d);
-  m.template density<7>(p, Ns, lds);
+  m.template density_stencil<0>(x, d, nullptr, Ns, lds);
   rhs_from_plasma<7>(cm, x, x + 3, w, d, p, Ns, rhs, dk, dw, B);
 }
 
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(64) void trace_kernel(const M *__restrict__ mp, con
     if (__any(needinit)) {
       double p7[7][3], d7[3], N7[7][4];
       stencil_points<7>(x, P.del, p7, d7);
-      m.template density<7>(p7, N7, lds);
+      m.template density_stencil<0>(x, d7, nullptr, N7, lds);
       if (needinit) {
         double B0[3];
         bfield(cm.fld, x[0], x[1], x[2], B0);
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(64) void trace_kernel(const M *__restrict__ mp, con
       pp[NPOST - 1][1] = est1[1];
       pp[NPOST - 1][2] = est1[2];
     }
-    m.template density<NPOST>(pp, NP_, lds);
+    m.template density_stencil<NPOST - 7>(est2, dpost, FIXED ? nullptr : est1, NP_, lds);
     PointState ps2;
 #pragma unroll
     for (int s = 0; s < 4; ++s) ps2.Ns[s] = NP_[0][s];

@@ -153,6 +153,20 @@ struct NgoModel {
 #pragma unroll
     for (int i = 0; i < NP; ++i) dens_point(p[i][0], p[i][1], p[i][2], Ns[i]);
   }
+  template <int NE>
+  __device__ __forceinline__ void density_stencil(const double c[3], const double d[3], const double *extra,
+                                                  double (&Ns)[7 + NE][4], double *) const {
+    dens_point(c[0], c[1], c[2], Ns[0]);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      double pp[3] = {c[0], c[1], c[2]}, pm[3] = {c[0], c[1], c[2]};
+      pp[a] = c[a] + d[a];
+      pm[a] = c[a] - d[a];
+      dens_point(pp[0], pp[1], pp[2], Ns[1 + 2 * a]);
+      dens_point(pm[0], pm[1], pm[2], Ns[2 + 2 * a]);
+    }
+    if (NE) dens_point(extra[0], extra[1], extra[2], Ns[7 + NE - 1]);
+  }
 };
 
 // =============================================================================================
@@ -245,6 +259,127 @@ struct InterpModel {
     }
   }
 
+  // Stage one species' coefficient rows of all 64 lanes into the LDS tile (see the layout note in density()).
+  __device__ __forceinline__ void stage_species(int cell, int s, double *lds) const {
+    const int lane = threadIdx.x;
+    const int half = lane >> 5, pchunk = lane & 31;
+    __syncthreads(); // previous readers of the tile are done (block == one wave)
+#pragma unroll 8
+    for (int t = 0; t < 32; ++t) {
+      int c0 = __builtin_amdgcn_readlane(cell, 2 * t), c1 = __builtin_amdgcn_readlane(cell, 2 * t + 1);
+      int cj_ = half ? c1 : c0;
+      int q = (pchunk - (2 * t + half)) & 31;
+      const double *src = coef + ((size_t)cj_ * (size_t)nspec + (size_t)s) * 64 + 2 * q;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                       (__attribute__((address_space(3))) void *)(lds + t * 128), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // The 7-point stencil of evalrhs (centre, x+-, y+-, z+-) plus NE (0/1) free points, all in one cell:
+  // points that share a coordinate share the partial Horner sums, so a species costs 252 (+68 per free point)
+  // FMAs instead of 68 per point.  Per point the operations and their order are exactly those of eval<>.
+  // X = {x0, x+, x-} local coordinates (same for Y, Z); E = local coordinates of the free point.
+  template <int NE, class Chunk>
+  __device__ __forceinline__ static void eval_stencil(Chunk chunk, const double (&X)[3], const double (&Y)[3],
+                                                      const double (&Z)[3], const double (&E)[3],
+                                                      double (&out)[7 + NE]) {
+    double vz[7 + NE];
+#pragma unroll
+    for (int i = 0; i < 7 + NE; ++i) vz[i] = 0.0;
+#pragma unroll
+    for (int k = 3; k >= 0; --k) {
+      double vc = 0.0, vxp = 0.0, vxm = 0.0, vyp = 0.0, vym = 0.0, ve = 0.0;
+#pragma unroll
+      for (int j = 3; j >= 0; --j) {
+        const int q = 2 * j + 8 * k;
+        double2 lo = chunk(q), hi = chunk(q + 1);
+        double h0 = fma(fma(fma(hi.y, X[0], hi.x), X[0], lo.y), X[0], lo.x);
+        double hp = fma(fma(fma(hi.y, X[1], hi.x), X[1], lo.y), X[1], lo.x);
+        double hm = fma(fma(fma(hi.y, X[2], hi.x), X[2], lo.y), X[2], lo.x);
+        vc = fma(vc, Y[0], h0);
+        vxp = fma(vxp, Y[0], hp);
+        vxm = fma(vxm, Y[0], hm);
+        vyp = fma(vyp, Y[1], h0);
+        vym = fma(vym, Y[2], h0);
+        if (NE) {
+          double he = fma(fma(fma(hi.y, E[0], hi.x), E[0], lo.y), E[0], lo.x);
+          ve = fma(ve, E[1], he);
+        }
+      }
+      vz[0] = fma(vz[0], Z[0], vc);
+      vz[1] = fma(vz[1], Z[0], vxp);
+      vz[2] = fma(vz[2], Z[0], vxm);
+      vz[3] = fma(vz[3], Z[0], vyp);
+      vz[4] = fma(vz[4], Z[0], vym);
+      vz[5] = fma(vz[5], Z[1], vc);
+      vz[6] = fma(vz[6], Z[2], vc);
+      if (NE) vz[7 + NE - 1] = fma(vz[7 + NE - 1], E[2], ve);
+    }
+#pragma unroll
+    for (int i = 0; i < 7 + NE; ++i) out[i] = vz[i];
+  }
+
+  // Densities at the evalrhs stencil around c (offsets d) and, when NE == 1, at one more point `extra`.
+  // Ns[0] centre, Ns[1+2a] = c + d_a e_a, Ns[2+2a] = c - d_a e_a, Ns[7] = extra.
+  template <int NE>
+  __device__ __forceinline__ void density_stencil(const double c[3], const double d[3], const double *extra,
+                                                  double (&Ns)[7 + NE][4], double *lds) const {
+    const int lane = threadIdx.x;
+    double X[3], Y[3], Z[3], E[3] = {0.0, 0.0, 0.0};
+    const int ci = ax.locate(c[0], X[0]), cj = ay.locate(c[1], Y[0]), ck = az.locate(c[2], Z[0]);
+    bool same = true;
+    same = same && (ax.locate(c[0] + d[0], X[1]) == ci) && (ax.locate(c[0] - d[0], X[2]) == ci);
+    same = same && (ay.locate(c[1] + d[1], Y[1]) == cj) && (ay.locate(c[1] - d[1], Y[2]) == cj);
+    same = same && (az.locate(c[2] + d[2], Z[1]) == ck) && (az.locate(c[2] - d[2], Z[2]) == ck);
+    bool extra_same = true;
+    if (NE) {
+      extra_same = (ax.locate(extra[0], E[0]) == ci) && (ay.locate(extra[1], E[1]) == cj) && (az.locate(extra[2], E[2]) == ck);
+    }
+    const int cell = cell_id(ci, cj, ck);
+    double acc[7 + NE][4];
+#pragma unroll
+    for (int i = 0; i < 7 + NE; ++i)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[i][k] = 0.0;
+    const double2 *mine = reinterpret_cast<const double2 *>(lds) + lane * 32;
+    for (int s = 0; s < nspec; ++s) {
+      stage_species(cell, s, lds);
+      double o[7 + NE];
+      eval_stencil<NE>([&](int q) { return mine[(q + lane) & 31]; }, X, Y, Z, E, o);
+#pragma unroll
+      for (int i = 0; i < 7 + NE; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[i][k] = (k == s) ? o[i] : acc[i][k];
+    }
+    // rare: a stencil point (offsets ~1e-6 |x| against cells of ~1e5..1e6 m) or the free point lies in another cell
+    if (__any(!same || !extra_same)) {
+      if (!same) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int sg = 0; sg < 2; ++sg) {
+            double pt[3] = {c[0], c[1], c[2]}, t[4] = {0.0, 0.0, 0.0, 0.0};
+            pt[a] = sg ? c[a] - d[a] : c[a] + d[a];
+            point_direct(pt[0], pt[1], pt[2], t);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[1 + 2 * a + sg][k] = t[k];
+          }
+      }
+      if (NE && !extra_same) {
+        double t[4] = {0.0, 0.0, 0.0, 0.0};
+        point_direct(extra[0], extra[1], extra[2], t);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[7 + NE - 1][k] = t[k];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 7 + NE; ++i)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) Ns[i][k] = (k < nspec) ? exp(acc[i][k]) : 0.0; // Ns = exp(Ns) (:206)
+  }
+
   template <int NP>
   __device__ __forceinline__ void density(const double (&p)[NP][3], double (&Ns)[NP][4], double *lds) const {
     const int lane = threadIdx.x;
@@ -271,21 +406,9 @@ struct InterpModel {
     // physical chunk (q + j) & 31 so that the 16-lane groups of ds_read_b128 hit 16 different bank slots.
     // Filled by LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B = two rows per instruction, no VGPR staging,
     // all 32 instructions of a species in flight together); the rotation is applied on the source address.
-    const int half = lane >> 5, pchunk = lane & 31;
     const double2 *mine = reinterpret_cast<const double2 *>(lds) + lane * 32;
     for (int s = 0; s < nspec; ++s) {
-      __syncthreads(); // previous readers of the tile are done (block == one wave)
-#pragma unroll 8
-      for (int t = 0; t < 32; ++t) {
-        int c0 = __builtin_amdgcn_readlane(cell, 2 * t), c1 = __builtin_amdgcn_readlane(cell, 2 * t + 1);
-        int cj_ = half ? c1 : c0;
-        int q = (pchunk - (2 * t + half)) & 31;
-        const double *src = coef + ((size_t)cj_ * (size_t)nspec + (size_t)s) * 64 + 2 * q;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                         (__attribute__((address_space(3))) void *)(lds + t * 128), 16, 0, 0);
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
+      stage_species(cell, s, lds);
       double o[NP];
       eval<NP>([&](int q) { return mine[(q + lane) & 31]; }, xl, yl, zl, o);
       // s is a run-time loop index: select statically so that acc stays in registers (no scratch)

@@ -192,6 +192,29 @@ struct ScatteredModel {
     }
   }
 
+  template <int NE>
+  __device__ __forceinline__ void density_stencil(const double c[3], const double d[3], const double *extra,
+                                                  double (&Ns)[7 + NE][4], double *) const {
+    double p[7 + NE][3];
+#pragma unroll
+    for (int i = 0; i < 7 + NE; ++i) {
+      p[i][0] = c[0];
+      p[i][1] = c[1];
+      p[i][2] = c[2];
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      p[1 + 2 * a][a] = c[a] + d[a];
+      p[2 + 2 * a][a] = c[a] - d[a];
+    }
+    if (NE) {
+      p[7 + NE - 1][0] = extra[0];
+      p[7 + NE - 1][1] = extra[1];
+      p[7 + NE - 1][2] = extra[2];
+    }
+    density<7 + NE>(p, Ns, nullptr);
+  }
+
   template <int NP>
   __device__ __forceinline__ void density(const double (&p)[NP][3], double (&Ns)[NP][4], double *) const {
 #pragma unroll
