@@ -49,7 +49,7 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    path = _build.LIB
+    path = os.environ.get("SRT_LIB_OVERRIDE") or _build.LIB  # override: A/B builds of the same sources (tools/ab.sh)
     if not os.path.exists(path):
         _build.build()
     if not os.path.exists(path):
