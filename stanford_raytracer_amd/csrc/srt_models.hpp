@@ -10,7 +10,18 @@
 namespace srt {
 
 constexpr int WAVE = 64;
-constexpr int TILE_DOUBLES = WAVE * 64; // one species' coefficients for all 64 lanes: 32 KiB per wave
+// LDS tile of the interp model: a ring of RING units; one unit = one k-plane (16 coefficients = 128 B) of one
+// species for all 64 lanes = 8 KiB.  TILE_PAD_BYTES of head room in front: the immediate offset of an LDS-DMA load
+// shifts the LDS address as well as the global one (probed: tools/probes/dma_probe.hip), so destinations are
+// biased by -imm.  34 KiB per wave, 4 waves per CU.
+constexpr int UNIT_BYTES = WAVE * 128;
+constexpr int RING = 4;
+constexpr int TILE_PAD_BYTES = 2048;
+constexpr int TILE_DOUBLES = (RING * UNIT_BYTES + TILE_PAD_BYTES) / 8;
+
+typedef double d2_t __attribute__((ext_vector_type(2)));
+#define SRT_AS1 __attribute__((address_space(1)))
+#define SRT_AS3 __attribute__((address_space(3)))
 
 // =============================================================================================
 // modelnum = 1: Ngo diffusive-equilibrium model.
@@ -259,74 +270,134 @@ struct InterpModel {
     }
   }
 
-  // Stage one species' coefficient rows of all 64 lanes into the LDS tile (see the layout note in density()).
-  __device__ __forceinline__ void stage_species(int cell, int s, double *lds) const {
+  // ------------------------------------------------------------------------------------------
+  // Staging of coefficient blocks through the LDS ring.
+  //
+  // Unit (s, k) = coefficients a[16k .. 16k+15] of species s (8 chunks of 16 B = one aligned 128-B line per lane).
+  // LDS image of a unit: 64 rows of 128 B; lane j owns row slot 8*(j&7) + (j>>3) and finds logical chunk q at
+  // physical chunk (q + j) & 7, so the 16-lane groups of ds_read_b128 ({0-3,12-15,20-27}, ...) touch 16 different
+  // 16-B bank slots (row parity = (j>>3)&1 selects the half of the 256-B bank row): conflict-free.
+  // Filled by LDS-DMA: instruction t of a unit writes 1 KiB = row slots 8t..8t+7; its lane L therefore carries
+  // chunk (L&7) of the row of lane (L&56)+t.  The per-lane source addresses depend only on the cells, so they are
+  // built ONCE per density call (two ds_bpermute per instruction) and serve all 4*nspec units: the unit is
+  // selected by the 12-bit immediate offset (k*128, +512 to reach into the next species).
+  __device__ __forceinline__ void stage_prepare(int cell, unsigned long long (&a)[8]) const {
     const int lane = threadIdx.x;
-    const int half = lane >> 5, pchunk = lane & 31;
-    __syncthreads(); // previous readers of the tile are done (block == one wave)
-#pragma unroll 8
-    for (int t = 0; t < 32; ++t) {
-      int c0 = __builtin_amdgcn_readlane(cell, 2 * t), c1 = __builtin_amdgcn_readlane(cell, 2 * t + 1);
-      int cj_ = half ? c1 : c0;
-      int q = (pchunk - (2 * t + half)) & 31;
-      const double *src = coef + ((size_t)cj_ * (size_t)nspec + (size_t)s) * 64 + 2 * q;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                       (__attribute__((address_space(3))) void *)(lds + t * 128), 16, 0, 0);
+    const unsigned long long base =
+        reinterpret_cast<unsigned long long>(coef) + (unsigned long long)(unsigned)cell * (unsigned long long)(nspec * 512);
+    const int blo = (int)(unsigned)base, bhi = (int)(unsigned)(base >> 32);
+    const int p = lane & 7, g = lane & 56;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int src = (g + t) << 2;
+      const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(src, blo);
+      const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute(src, bhi);
+      a[t] = (((unsigned long long)hi << 32) | (unsigned long long)lo) + (unsigned long long)(((p - t) & 7) << 4);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+  }
+  // LDS byte addresses of this lane's 8 logical chunks inside ring buffer 0
+  __device__ __forceinline__ static void read_addrs(double *lds, unsigned (&ra)[8]) {
+    const int lane = threadIdx.x;
+    const unsigned base = (unsigned)(unsigned long long)((SRT_AS3 char *)lds) + TILE_PAD_BYTES +
+                          (unsigned)((8 * (lane & 7) + (lane >> 3)) * 128);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) ra[q] = base + (unsigned)(((q + lane) & 7) << 4);
+  }
+  // DMA of one unit into ring buffer J; IMM = byte offset of the unit relative to the addresses in a[]
+  template <int IMM, int J>
+  __device__ __forceinline__ static void issue_unit(const unsigned long long (&a)[8], double *lds) {
+    SRT_AS3 char *ring = (SRT_AS3 char *)lds + TILE_PAD_BYTES;
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+      __builtin_amdgcn_global_load_lds((const SRT_AS1 void *)a[t], (SRT_AS3 void *)(ring + (J * UNIT_BYTES + t * 1024 - IMM)),
+                                       16, IMM, 0);
+  }
+  template <int N>
+  __device__ __forceinline__ static void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+  }
+  // All 8 chunks of a unit from ring buffer J into registers.  Inline asm on purpose: the compiler's wait-count
+  // pass makes every LDS load it can see wait for ALL LDS-DMA in flight, which would serialise the ring.
+  template <int J>
+  __device__ __forceinline__ static void read_unit(const unsigned (&ra)[8], d2_t (&c)[8]) {
+    asm volatile("ds_read_b128 %0, %8 offset:%16\n\t"
+                 "ds_read_b128 %1, %9 offset:%16\n\t"
+                 "ds_read_b128 %2, %10 offset:%16\n\t"
+                 "ds_read_b128 %3, %11 offset:%16\n\t"
+                 "ds_read_b128 %4, %12 offset:%16\n\t"
+                 "ds_read_b128 %5, %13 offset:%16\n\t"
+                 "ds_read_b128 %6, %14 offset:%16\n\t"
+                 "ds_read_b128 %7, %15 offset:%16\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3]), "=&v"(c[4]), "=&v"(c[5]), "=&v"(c[6]), "=&v"(c[7])
+                 : "v"(ra[0]), "v"(ra[1]), "v"(ra[2]), "v"(ra[3]), "v"(ra[4]), "v"(ra[5]), "v"(ra[6]), "v"(ra[7]),
+                   "n"(J * UNIT_BYTES)
+                 : "memory");
   }
 
-  // The 7-point stencil of evalrhs (centre, x+-, y+-, z+-) plus NE (0/1) free points, all in one cell:
-  // points that share a coordinate share the partial Horner sums, so a species costs 252 (+68 per free point)
-  // FMAs instead of 68 per point.  Per point the operations and their order are exactly those of eval<>.
-  // X = {x0, x+, x-} local coordinates (same for Y, Z); E = local coordinates of the free point.
-  template <int NE, class Chunk>
-  __device__ __forceinline__ static void eval_stencil(Chunk chunk, const double (&X)[3], const double (&Y)[3],
-                                                      const double (&Z)[3], const double (&E)[3],
-                                                      double (&out)[7 + NE]) {
-    double vz[7 + NE];
+  // One k-plane of tricubic_eval (libtricubic.f95:658-695, derx=dery=derz=0) for the 7-point stencil of evalrhs
+  // (centre, x+-, y+-, z+-) plus NE (0/1) free points, all in one cell.  c[2j], c[2j+1] = a(0..3 + 4j + 16k).
+  // Points that share a coordinate share the partial Horner sums; per point the operations and their order are
+  // exactly those of a plain nested Horner evaluation (k outer, j middle, i inner).
+  template <int NE>
+  __device__ __forceinline__ static void plane_stencil(const d2_t (&c)[8], const double (&X)[3], const double (&Y)[3],
+                                                       const double (&Z)[3], const double (&E)[3],
+                                                       double (&vz)[7 + NE]) {
+    double vc = 0.0, vxp = 0.0, vxm = 0.0, vyp = 0.0, vym = 0.0, ve = 0.0;
 #pragma unroll
-    for (int i = 0; i < 7 + NE; ++i) vz[i] = 0.0;
-#pragma unroll
-    for (int k = 3; k >= 0; --k) {
-      double vc = 0.0, vxp = 0.0, vxm = 0.0, vyp = 0.0, vym = 0.0, ve = 0.0;
-#pragma unroll
-      for (int j = 3; j >= 0; --j) {
-        const int q = 2 * j + 8 * k;
-        double2 lo = chunk(q), hi = chunk(q + 1);
-        double h0 = fma(fma(fma(hi.y, X[0], hi.x), X[0], lo.y), X[0], lo.x);
-        double hp = fma(fma(fma(hi.y, X[1], hi.x), X[1], lo.y), X[1], lo.x);
-        double hm = fma(fma(fma(hi.y, X[2], hi.x), X[2], lo.y), X[2], lo.x);
-        vc = fma(vc, Y[0], h0);
-        vxp = fma(vxp, Y[0], hp);
-        vxm = fma(vxm, Y[0], hm);
-        vyp = fma(vyp, Y[1], h0);
-        vym = fma(vym, Y[2], h0);
-        if (NE) {
-          double he = fma(fma(fma(hi.y, E[0], hi.x), E[0], lo.y), E[0], lo.x);
-          ve = fma(ve, E[1], he);
-        }
+    for (int j = 3; j >= 0; --j) {
+      const d2_t lo = c[2 * j], hi = c[2 * j + 1];
+      double h0 = fma(fma(fma(hi.y, X[0], hi.x), X[0], lo.y), X[0], lo.x);
+      double hp = fma(fma(fma(hi.y, X[1], hi.x), X[1], lo.y), X[1], lo.x);
+      double hm = fma(fma(fma(hi.y, X[2], hi.x), X[2], lo.y), X[2], lo.x);
+      vc = fma(vc, Y[0], h0);
+      vxp = fma(vxp, Y[0], hp);
+      vxm = fma(vxm, Y[0], hm);
+      vyp = fma(vyp, Y[1], h0);
+      vym = fma(vym, Y[2], h0);
+      if (NE) {
+        double he = fma(fma(fma(hi.y, E[0], hi.x), E[0], lo.y), E[0], lo.x);
+        ve = fma(ve, E[1], he);
       }
-      vz[0] = fma(vz[0], Z[0], vc);
-      vz[1] = fma(vz[1], Z[0], vxp);
-      vz[2] = fma(vz[2], Z[0], vxm);
-      vz[3] = fma(vz[3], Z[0], vyp);
-      vz[4] = fma(vz[4], Z[0], vym);
-      vz[5] = fma(vz[5], Z[1], vc);
-      vz[6] = fma(vz[6], Z[2], vc);
-      if (NE) vz[7 + NE - 1] = fma(vz[7 + NE - 1], E[2], ve);
+    }
+    vz[0] = fma(vz[0], Z[0], vc);
+    vz[1] = fma(vz[1], Z[0], vxp);
+    vz[2] = fma(vz[2], Z[0], vxm);
+    vz[3] = fma(vz[3], Z[0], vyp);
+    vz[4] = fma(vz[4], Z[0], vym);
+    vz[5] = fma(vz[5], Z[1], vc);
+    vz[6] = fma(vz[6], Z[2], vc);
+    if (NE) vz[7 + NE - 1] = fma(vz[7 + NE - 1], E[2], ve);
+  }
+  // the same plane for NP unrelated points of one cell
+  template <int NP>
+  __device__ __forceinline__ static void plane_points(const d2_t (&c)[8], const double (&x)[NP], const double (&y)[NP],
+                                                      const double (&z)[NP], double (&vz)[NP]) {
+    double vy[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) vy[i] = 0.0;
+#pragma unroll
+    for (int j = 3; j >= 0; --j) {
+      const d2_t lo = c[2 * j], hi = c[2 * j + 1];
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        double vx = fma(fma(fma(hi.y, x[i], hi.x), x[i], lo.y), x[i], lo.x);
+        vy[i] = fma(vy[i], y[i], vx);
+      }
     }
 #pragma unroll
-    for (int i = 0; i < 7 + NE; ++i) out[i] = vz[i];
+    for (int i = 0; i < NP; ++i) vz[i] = fma(vz[i], z[i], vy[i]);
   }
 
   // Densities at the evalrhs stencil around c (offsets d) and, when NE == 1, at one more point `extra`.
   // Ns[0] centre, Ns[1+2a] = c + d_a e_a, Ns[2+2a] = c - d_a e_a, Ns[7] = extra.
+  //
+  // The 4*nspec units of the call stream through the ring with a lookahead of three: while the lane evaluates
+  // plane k of species s from buffer (3-k), the DMA of the next three units is in flight (the loads of one wave
+  // retire in issue order, so s_waitcnt vmcnt(24) = "all but the youngest three units have landed").
   template <int NE>
   __device__ __forceinline__ void density_stencil(const double c[3], const double d[3], const double *extra,
                                                   double (&Ns)[7 + NE][4], double *lds) const {
-    const int lane = threadIdx.x;
     double X[3], Y[3], Z[3], E[3] = {0.0, 0.0, 0.0};
     const int ci = ax.locate(c[0], X[0]), cj = ay.locate(c[1], Y[0]), ck = az.locate(c[2], Z[0]);
     bool same = true;
@@ -337,34 +408,67 @@ struct InterpModel {
     if (NE) {
       extra_same = (ax.locate(extra[0], E[0]) == ci) && (ay.locate(extra[1], E[1]) == cj) && (az.locate(extra[2], E[2]) == ck);
     }
-    const int cell = cell_id(ci, cj, ck);
+    unsigned long long a[8];
+    unsigned ra[8];
+    stage_prepare(cell_id(ci, cj, ck), a);
+    read_addrs(lds, ra);
+    issue_unit<384, 0>(a, lds); // species 0: planes 3, 2, 1 -> buffers 0, 1, 2
+    issue_unit<256, 1>(a, lds);
+    issue_unit<128, 2>(a, lds);
     double acc[7 + NE][4];
 #pragma unroll
     for (int i = 0; i < 7 + NE; ++i)
 #pragma unroll
       for (int k = 0; k < 4; ++k) acc[i][k] = 0.0;
-    const double2 *mine = reinterpret_cast<const double2 *>(lds) + lane * 32;
+#pragma unroll 1
     for (int s = 0; s < nspec; ++s) {
-      stage_species(cell, s, lds);
-      double o[7 + NE];
-      eval_stencil<NE>([&](int q) { return mine[(q + lane) & 31]; }, X, Y, Z, E, o);
+      const bool last = s + 1 >= nspec; // wave-uniform
+      double vz[7 + NE];
+#pragma unroll
+      for (int i = 0; i < 7 + NE; ++i) vz[i] = 0.0;
+      d2_t cf[8];
+      issue_unit<0, 3>(a, lds); // plane 0 of this species
+      wait_vm<24>();
+      read_unit<0>(ra, cf);
+      plane_stencil<NE>(cf, X, Y, Z, E, vz); // k = 3
+      if (!last) {
+        issue_unit<512 + 384, 0>(a, lds); // plane 3 of the next species
+        wait_vm<24>();
+      } else wait_vm<16>();
+      read_unit<1>(ra, cf);
+      plane_stencil<NE>(cf, X, Y, Z, E, vz); // k = 2
+      if (!last) {
+        issue_unit<512 + 256, 1>(a, lds);
+        wait_vm<24>();
+      } else wait_vm<8>();
+      read_unit<2>(ra, cf);
+      plane_stencil<NE>(cf, X, Y, Z, E, vz); // k = 1
+      if (!last) {
+        issue_unit<512 + 128, 2>(a, lds);
+        wait_vm<24>();
+      } else wait_vm<0>();
+      read_unit<3>(ra, cf);
+      plane_stencil<NE>(cf, X, Y, Z, E, vz); // k = 0
+      // s is a run-time loop index: select statically so that acc stays in registers (no scratch)
 #pragma unroll
       for (int i = 0; i < 7 + NE; ++i)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) acc[i][k] = (k == s) ? o[i] : acc[i][k];
+        for (int k = 0; k < 4; ++k) acc[i][k] = (k == s) ? vz[i] : acc[i][k];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) a[t] += 512;
     }
     // rare: a stencil point (offsets ~1e-6 |x| against cells of ~1e5..1e6 m) or the free point lies in another cell
     if (__any(!same || !extra_same)) {
       if (!same) {
 #pragma unroll
-        for (int a = 0; a < 3; ++a)
+        for (int ax_ = 0; ax_ < 3; ++ax_)
 #pragma unroll
           for (int sg = 0; sg < 2; ++sg) {
             double pt[3] = {c[0], c[1], c[2]}, t[4] = {0.0, 0.0, 0.0, 0.0};
-            pt[a] = sg ? c[a] - d[a] : c[a] + d[a];
+            pt[ax_] = sg ? c[ax_] - d[ax_] : c[ax_] + d[ax_];
             point_direct(pt[0], pt[1], pt[2], t);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) acc[1 + 2 * a + sg][k] = t[k];
+            for (int k = 0; k < 4; ++k) acc[1 + 2 * ax_ + sg][k] = t[k];
           }
       }
       if (NE && !extra_same) {
@@ -380,10 +484,10 @@ struct InterpModel {
       for (int k = 0; k < 4; ++k) Ns[i][k] = (k < nspec) ? exp(acc[i][k]) : 0.0; // Ns = exp(Ns) (:206)
   }
 
+  // NP unrelated points (layered kernels; not performance-critical): same units, no lookahead.
   template <int NP>
   __device__ __forceinline__ void density(const double (&p)[NP][3], double (&Ns)[NP][4], double *lds) const {
-    const int lane = threadIdx.x;
-    // cell of point 0; the other points normally share it (FD offsets are ~1e-6 |x| << cell size)
+    // cell of point 0; the other points normally share it
     double xl[NP], yl[NP], zl[NP];
     int ci = ax.locate(p[0][0], xl[0]);
     int cj = ay.locate(p[0][1], yl[0]);
@@ -396,26 +500,40 @@ struct InterpModel {
       int c3 = az.locate(p[i][2], zl[i]);
       if (c1 != ci || c2 != cj || c3 != ck) strag |= 1u << i;
     }
-    const int cell = cell_id(ci, cj, ck);
+    unsigned long long a[8];
+    unsigned ra[8];
+    stage_prepare(cell_id(ci, cj, ck), a);
+    read_addrs(lds, ra);
     double acc[NP][4];
 #pragma unroll
     for (int i = 0; i < NP; ++i)
 #pragma unroll
       for (int k = 0; k < 4; ++k) acc[i][k] = 0.0;
-    // LDS tile: row j (512 B) = lane j's 64 coefficients of one species as 32 chunks of 16 B, chunk q stored at
-    // physical chunk (q + j) & 31 so that the 16-lane groups of ds_read_b128 hit 16 different bank slots.
-    // Filled by LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B = two rows per instruction, no VGPR staging,
-    // all 32 instructions of a species in flight together); the rotation is applied on the source address.
-    const double2 *mine = reinterpret_cast<const double2 *>(lds) + lane * 32;
+#pragma unroll 1
     for (int s = 0; s < nspec; ++s) {
-      stage_species(cell, s, lds);
-      double o[NP];
-      eval<NP>([&](int q) { return mine[(q + lane) & 31]; }, xl, yl, zl, o);
-      // s is a run-time loop index: select statically so that acc stays in registers (no scratch)
+      double vz[NP];
+#pragma unroll
+      for (int i = 0; i < NP; ++i) vz[i] = 0.0;
+      d2_t cf[8];
+      issue_unit<384, 0>(a, lds);
+      issue_unit<256, 1>(a, lds);
+      issue_unit<128, 2>(a, lds);
+      issue_unit<0, 3>(a, lds);
+      wait_vm<0>();
+      read_unit<0>(ra, cf);
+      plane_points<NP>(cf, xl, yl, zl, vz);
+      read_unit<1>(ra, cf);
+      plane_points<NP>(cf, xl, yl, zl, vz);
+      read_unit<2>(ra, cf);
+      plane_points<NP>(cf, xl, yl, zl, vz);
+      read_unit<3>(ra, cf);
+      plane_points<NP>(cf, xl, yl, zl, vz);
 #pragma unroll
       for (int i = 0; i < NP; ++i)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) acc[i][k] = (k == s) ? o[i] : acc[i][k];
+        for (int k = 0; k < 4; ++k) acc[i][k] = (k == s) ? vz[i] : acc[i][k];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) a[t] += 512;
     }
     if (__any(strag != 0)) {
 #pragma unroll
