@@ -389,9 +389,9 @@ extern "C" int srt_model_create_interp(int nspec, int nx, int ny, int nz, const 
   m->device_bytes = (int64_t)(ncell * nspec * 64 * sizeof(double));
   m->interp.coef = d_coef;
   m->interp.nspec = nspec;
-  m->interp.ax = Axis{bounds[0], dx, nx};
-  m->interp.ay = Axis{bounds[2], dy, ny};
-  m->interp.az = Axis{bounds[4], dz, nz};
+  m->interp.ax = Axis{bounds[0], dx, 1.0 / dx, nx};
+  m->interp.ay = Axis{bounds[2], dy, 1.0 / dy, ny};
+  m->interp.az = Axis{bounds[4], dz, 1.0 / dz, nz};
   fill_common(m->cm, nspec, qs, ms, yearday, msec);
   rc = model_finish(m);
   if (rc) {

@@ -40,6 +40,19 @@ struct Common {
   double C; // speed of light as constants.f95:7 computes it
 };
 
+// a/b for operands well inside the exponent range (every division of the hot path: frequencies, densities,
+// field magnitudes, grid spacings).  This is the compiler's own fp64 division sequence -- v_rcp_f64, two Newton
+// steps on the reciprocal, quotient, one residual correction -- without the v_div_scale / v_div_fmas /
+// v_div_fixup wrapper that only matters for operands or quotients near the ends of the exponent range, so the
+// result is bit-identical to a/b wherever that wrapper would not have scaled (8 instructions instead of 11).
+__device__ __forceinline__ double fdiv(double a, double b) {
+  double r = __builtin_amdgcn_rcp(b);
+  r = fma(fma(-b, r, 1.0), r, r);
+  r = fma(fma(-b, r, 1.0), r, r);
+  double q = a * r;
+  return fma(fma(-b, q, a), r, q);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Dipole B in SM coordinates, then the adapters' GSM round trip through float32 nT
 // (bmodel_dipole.f95:20-48; interp_dens_model_adapter.f95:243-267 and its twins; SURVEY A-8).
@@ -48,7 +61,7 @@ __device__ __forceinline__ void bfield(const FieldConst &f, double x, double y, 
   double rho2 = x * x + y * y;
   double r2 = rho2 + z * z;
   double r = sqrt(r2);
-  double k = f.bo_re3 / (r2 * r2 * r);
+  double k = fdiv(f.bo_re3, r2 * r2 * r);
   double bx = -3.0 * k * x * z;
   double by = -3.0 * k * y * z;
   double bz = k * (rho2 - 2.0 * z * z);
@@ -81,7 +94,7 @@ __device__ __forceinline__ Stix stix_parameters(const Species &sp, double w, con
     double wps2 = Ns[s] * sp.c[s];
     double wcs = sp.g[s] * Bmag;
     double a = w + wcs, b = w - wcs;
-    double t = wps2 / (w * a * b); // one division serves both the R and the L term
+    double t = fdiv(wps2, w * a * b); // one division serves both the R and the L term
     sr += t * b;                   // wps2/(w*(w+wcs))
     sl += t * a;                   // wps2/(w*(w-wcs))
     sw += wps2;
@@ -90,7 +103,7 @@ __device__ __forceinline__ Stix stix_parameters(const Species &sp, double w, con
   Stix st;
   st.R = 1.0 - sr;
   st.L = 1.0 - sl;
-  st.P = 1.0 - sw / (w * w);
+  st.P = 1.0 - fdiv(sw, w * w);
   st.S = 0.5 * (st.R + st.L);
   st.D = 0.5 * (st.R - st.L);
   st.RL = st.R * st.L;
@@ -107,7 +120,7 @@ __device__ __forceinline__ double dispersion_F(const Stix &st, const double n[3]
                                                double B2) {
   double nmag2 = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
   double nb = n[0] * B[0] + n[1] * B[1] + n[2] * B[2];
-  double cos2 = (nb * nb) / (nmag2 * B2);
+  double cos2 = fdiv(nb * nb, nmag2 * B2);
   double sin2 = 1.0 - cos2;
   double A = st.S * sin2 + st.P * cos2;
   double Bq = st.RL * sin2 + st.PS * (1.0 + cos2);
@@ -131,7 +144,7 @@ __device__ __forceinline__ void dFdk(const Stix &st, const double k[3], double c
     double nm[3] = {np[0], np[1], np[2]};
     np[c] = (k[c] + d) * cw;
     nm[c] = (k[c] - d) * cw;
-    out[c] = (dispersion_F(st, np, B, B2) - dispersion_F(st, nm, B, B2)) / d * 0.5;
+    out[c] = fdiv(dispersion_F(st, np, B, B2) - dispersion_F(st, nm, B, B2), d) * 0.5;
   }
 }
 
@@ -144,10 +157,10 @@ __device__ __forceinline__ double dFdw(const Species &sp, const double k[3], dou
   double wp = w + d, wm = w - d;
   Stix sp_ = stix_parameters(sp, wp, Ns, Bmag);
   Stix sm_ = stix_parameters(sp, wm, Ns, Bmag);
-  double cp = C / wp, cm = C / wm;
+  double cp = fdiv(C, wp), cm = fdiv(C, wm);
   double np[3] = {k[0] * cp, k[1] * cp, k[2] * cp};
   double nm[3] = {k[0] * cm, k[1] * cm, k[2] * cm};
-  return (dispersion_F(sp_, np, B, B2) - dispersion_F(sm_, nm, B, B2)) / d * 0.5;
+  return fdiv(dispersion_F(sp_, np, B, B2) - dispersion_F(sm_, nm, B, B2), d) * 0.5;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -58,7 +58,7 @@ __device__ __forceinline__ void rhs_from_plasma(const Common &cm, const double x
   double B2 = B[0] * B[0] + B[1] * B[1] + B[2] * B[2];
   double Bmag = sqrt(B2);
   Stix st0 = stix_parameters(cm.sp, w, Ns[0], Bmag);
-  double cw = cm.C / w;
+  double cw = fdiv(cm.C, w);
   dFdk(st0, k, cw, B, B2, dk);
   dw = dFdw(cm.sp, k, w, cm.C, Ns[0], B, B2, Bmag);
   double n[3] = {k[0] * cw, k[1] * cw, k[2] * cw};
@@ -75,9 +75,9 @@ __device__ __forceinline__ void rhs_from_plasma(const Common &cm, const double x
       Stix st = stix_parameters(cm.sp, w, Ns[i], sqrt(Bp2));
       Fpm[s] = dispersion_F(st, n, Bp, Bp2);
     }
-    dx[c] = (Fpm[0] - Fpm[1]) / d[c] * 0.5;
+    dx[c] = fdiv(Fpm[0] - Fpm[1], d[c]) * 0.5;
   }
-  double idw = 1.0 / dw;
+  double idw = fdiv(1.0, dw);
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     rhs[c] = -(dk[c] * idw);
@@ -128,15 +128,15 @@ __device__ __forceinline__ void rk_stages(const M &m, const Common &cm, const Ta
   }
 #pragma unroll 1
   for (int s = (r1 ? 1 : 0); s < tab.stages; ++s) {
-    double tmp[6];
+    double tmp[6], arow[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) arow[j] = tab.a[s][j]; // wave-uniform: one wide scalar load per stage
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
       double acc = 0.0;
 #pragma unroll
-      for (int j = 0; j < 5; ++j) {
-        double aj = tab.a[s][j]; // wave-uniform (scalar load)
-        if (j < s) acc += aj * ks[j][c];
-      }
+      for (int j = 0; j < 5; ++j)
+        if (j < s) acc += arow[j] * ks[j][c];
       tmp[c] = x[c] + acc;
     }
     double r[6];

@@ -194,14 +194,19 @@ struct NgoModel {
 // species by species through a 33 KB LDS tile with fully coalesced 512 B reads, and every lane
 // evaluates all its stencil points from the tile.
 struct Axis {
-  double min, del;
+  double min, del, rdel; // rdel = 1/del: only for the first guess of the cell search
   int n;
   // node i (0-based): real(i)*del + min, separately rounded like interp_dens_model_adapter.f95:93-95
-  __device__ __forceinline__ double node(int i) const { return __dadd_rn(__dmul_rn((double)i, del), min); }
+  // (the product must not be fused into the sum: the Fortran rounds it separately)
+  __device__ __forceinline__ double node(int i) const {
+#pragma clang fp contract(off)
+    double prod = (double)i * del;
+    return prod + min;
+  }
   // maxloc(.., mask = 0 <= (xi - x)) (libtricubic.f95:835-840): number of nodes <= xi, and the local
   // coordinate (:842-856)
   __device__ __forceinline__ int locate(double xi, double &xl) const {
-    double f = (xi - min) / del;
+    double f = (xi - min) * rdel;
     int g;
     if (!(f >= 0.0)) g = 0;
     else if (f >= (double)n) g = n;
@@ -209,7 +214,7 @@ struct Axis {
     // the quotient is within one node of the exact answer: one correction each way, no loops
     g += (g < n && node(g) <= xi) ? 1 : 0;
     g -= (g > 0 && node(g - 1) > xi) ? 1 : 0;
-    xl = (g >= 1 && g < n) ? (xi - node(g - 1)) / del : 0.0;
+    xl = (g >= 1 && g < n) ? fdiv(xi - node(g - 1), del) : 0.0;
     return g;
   }
 };

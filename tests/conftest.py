@@ -9,6 +9,12 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
+# One RK step of the interp model, GPU vs reference goldens (tests/test_gpu_parity.py::test_g3_single_steps).
+# Each bar is a small multiple of what the reference itself does under a 1e-13 relative perturbation of the step's
+# inputs (pinned by tests/test_oracle_golden.py::test_g3_interp_self_sensitivity).
+G3_INTERP_BARS = {"pos_median": 1e-7, "pos_max": 3e-5, "k_median": 1e-4, "k_p90": 1e-3, "k_max": 1e-2,
+                  "k_frac_tight": 0.15}
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs an MI355X (run on the GPU box with -m gpu)")

@@ -8,14 +8,15 @@ vectors, rung by rung (SURVEY.md A-9 ladder).  Tolerances are fp64 tolerances of
                         1-ulp differences by 1e8: the reference differs from its own FMA rebuild by 2e-8)
                         dF/dx: Ngo <= 1e-7; interp (del = 1e-6, float32 staircase in B, SURVEY A-8):
                         median <= 1e-7, 95th percentile <= 1e-5
-  G3 one RK step        position: median <= 1e-8 of |x|, max <= 1e-7 (interp, 16^3 grid: 1e-5); k: median <= 1e-7 of
-                        |k| (interp 1e-5).  Single float32-staircase flips and near-resonance-cone states give
-                        isolated outliers, exactly as they do between two builds of the reference
+  G3 one RK step        Ngo: position median <= 1e-8 of |x|, max <= 1e-7; k median <= 1e-7 of |k|.
+                        interp (16^3 grid): bars of conftest.G3_INTERP_BARS = the reference's own sensitivity to a
+                        1e-13 input perturbation (float32-staircase flips over the dF/dx stencil), pinned on the
+                        CPU by test_oracle_golden.py::test_g3_interp_self_sensitivity
 """
 import numpy as np
 import pytest
 
-from conftest import DELS, vrel
+from conftest import DELS, G3_INTERP_BARS, vrel
 
 pytestmark = pytest.mark.gpu
 MODELS = ["ngo", "ngoducts", "interp"]
@@ -107,10 +108,20 @@ def test_g3_single_steps(golden, gpu_models, name):
     g = gpu_models[name].rk_step(rows[:, 0:7], rows[:, 7], DELS[name])
     for o in (0, 7, 14):
         ex = vrel(g[:, o:o + 3], ref[:, o:o + 3])
-        assert np.median(ex) <= 1e-8 and ex.max() <= (1e-5 if name == "interp" else 1e-7)
         ek = vrel(g[:, o + 3:o + 6], ref[:, o + 3:o + 6])
-        assert np.median(ek) <= (1e-5 if name == "interp" else 1e-7)
-        assert ek.max() <= 1e-2
+        if name == "interp":
+            # Bars = the reference's OWN sensitivity: tests/test_oracle_golden.py::test_g3_interp_self_sensitivity
+            # perturbs the step inputs by 1e-13 and finds position median 2e-8 / max 7e-6 and k median 2e-5 /
+            # p90 1.4e-4 / max 6e-4, with only ~30 % of the samples untouched (<= 1e-7): a sample either sees the
+            # same float32 steps of B over the dF/dx stencil (SURVEY A-8) or one step flips.
+            b = G3_INTERP_BARS
+            assert np.median(ex) <= b["pos_median"] and ex.max() <= b["pos_max"]
+            assert np.median(ek) <= b["k_median"] and np.percentile(ek, 90) <= b["k_p90"] and ek.max() <= b["k_max"]
+            assert np.mean(ek <= 1e-7) >= b["k_frac_tight"]
+        else:
+            assert np.median(ex) <= 1e-8 and ex.max() <= 1e-7
+            assert np.median(ek) <= 1e-7
+            assert ek.max() <= 1e-2
         assert np.array_equal(g[:, o + 6], ref[:, o + 6])  # omega is carried unchanged
 
 

@@ -136,3 +136,28 @@ def test_g4_scattered_trajectories(golden, pointsfile):
     assert np.percentile(e, 90) <= 1e-9
     d1 = np.linalg.norm(rows[both, 1, 1:4] - ref_rows[both, 1, 1:4], axis=1) / np.linalg.norm(ref_rows[both, 1, 1:4], axis=1)
     assert np.median(d1) <= 1e-6  # dF/dx amplifies the 1e-13 summation-order differences of ln N by ~1e6
+
+
+def test_g3_interp_self_sensitivity(golden, oracle_models):
+    """The yardstick behind tests/conftest.py::G3_INTERP_BARS: how far one RK step of the reference's own
+    algorithm moves when its inputs are perturbed by 1e-13 (relative).  Central differences with a 1e-8 step and
+    the float32 round trip of B (SURVEY A-8) make the k increment jump by ~1e-5 of |k| for ~70 % of the samples,
+    so GPU-vs-reference agreement cannot be asked to be tighter than this."""
+    from conftest import G3_INTERP_BARS as bars, vrel
+
+    m = oracle_models["interp"]
+    rows, ref = golden["g3_interp_in"], golden["g3_interp_out"]
+    rng = np.random.default_rng(1)
+    pert = rows.copy()
+    pert[:, :6] *= 1 + 1e-13 * rng.standard_normal((len(rows), 6))
+    out = np.array([np.ravel(m.step(r[:7], r[7], DELS["interp"])) for r in pert])
+    ex = np.concatenate([vrel(out[:, o:o + 3], ref[:, o:o + 3]) for o in (7, 14)])
+    ek = np.concatenate([vrel(out[:, o + 3:o + 6], ref[:, o + 3:o + 6]) for o in (7, 14)])
+    # the reference's self-noise is within a decade of every bar (bars are not gratuitously loose) ...
+    assert bars["pos_median"] <= 100 * np.median(ex) and bars["pos_max"] <= 10 * ex.max()
+    assert bars["k_median"] <= 10 * np.median(ek) and bars["k_p90"] <= 10 * np.percentile(ek, 90)
+    assert bars["k_max"] <= 50 * ek.max()
+    # ... and below them (they are bars the reference itself would pass)
+    assert np.median(ex) <= bars["pos_median"] and ex.max() <= bars["pos_max"]
+    assert np.median(ek) <= bars["k_median"] and np.percentile(ek, 90) <= bars["k_p90"] and ek.max() <= bars["k_max"]
+    assert np.mean(ek <= 1e-7) >= bars["k_frac_tight"]
