@@ -45,7 +45,10 @@ def test_cli_config1_matches_reference_ray_file(tmp_path, cfgfiles, golden):
     r0 = ref[:, 2] == 0
     assert np.array_equal(mine[r0, 3:6], ref[r0, 3:6])
     assert vrel(mine[:, 3:6], ref[:, 3:6]).max() <= 1e-3         # row 100 of the ladder x10 (4e-5 -> 4e-4) with margin
-    assert vrel(mine[ref[:, 2] <= 0.0251, 3:6], ref[ref[:, 2] <= 0.0251, 3:6]).max() <= 1e-5
+    # rows 0 and 25 only: the survey ladder (reference vs its own FMA rebuild) gives 7e-8 after 10 steps and 4e-5
+    # after 100; single rays sit near 1e-5 at step 25 and move with any 1-ulp change.  This test is about the CLI and
+    # the .ray format; the parity bars proper (against the oracle's own sensitivity) are in test_gpu_trace.py
+    assert vrel(mine[ref[:, 2] <= 0.0251, 3:6], ref[ref[:, 2] <= 0.0251, 3:6]).max() <= 4e-5
     assert np.max(np.abs(mine[:, 28:32] - ref[:, 28:32]) / ref[:, 28:32]) <= 1e-2  # Ns along the diverging paths
 
     # the Fortran program over the bind(C) shim writes the same file through the same library
