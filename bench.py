@@ -64,6 +64,11 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    # one rank per GPU.  (Rehearsal on a 1-GPU box: SRT_BENCH_BACKEND=gloo --no-gather folds the ranks onto the
+    # devices that exist; RCCL itself refuses two ranks on one device.)
+    backend = os.environ.get("SRT_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -71,7 +76,10 @@ def main():
 
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     dev = torch.device("cuda", local_rank)
 
     from stanford_raytracer_amd import api, workloads as wl
@@ -210,8 +218,14 @@ def main():
             "config": {"workload": wname, "rays_per_gpu": nrays, "grid": grid_n, "maxsteps": p.maxsteps,
                        "outputper": p.outputper, "integrator": "rkf45 adaptive", "parallelism": "rays sharded x%d" % world,
                        "gather": bool(dist is not None and not args.no_gather)},
+            # achieved/frac: ALGORITHMIC bytes (every lookup counted at 2 KiB) / kernel time -- exceeds the
+            # HBM peak because consecutive lookups of a ray re-read the same block.  traffic: fabric-side bytes per
+            # launch from the PMC passes (profiles/traffic_*.json); traffic_GBs = traffic / kernel time is the physical
+            # rate to hold against the 8 TB/s peak (traffic_frac).
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_GBs": (traffic / (k_ms * 1e-3) / 1e9) if traffic else None,
+                         "traffic_frac": (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                          "kernel": "trace_kernel<%s,adaptive>" % kind, "kernel_ms": k_ms,
                          "algorithmic_bytes_per_accepted_step": ALGO_BYTES_PER_STEP[kind](p.outputper),
                          "accepted_steps_per_launch": steps_per_launch},
@@ -221,7 +235,7 @@ def main():
                        "stopcond_hist": {str(int(k)): int(v) for k, v in zip(*np.unique(stop, return_counts=True))},
                        "model_setup_s": setup_s, "model_device_GB": model.device_bytes / 1e9},
         }
-        out["cpu_baseline"] = cpu_baseline(args, kind, p, wl, pos0, dir0, w0, grid_n) if args.cpu_seconds > 0 else None
+        out["cpu_baseline"] = cpu_baseline(args, kind, p, wl, pos0, dir0, w0, grid_n) if (args.cpu_seconds > 0 and world == 1) else None
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -18,3 +18,4 @@ for C in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES
   timeout -k 10 400 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc_$N -- python3 bench.py --workload $WL --steps 1 --warmup 0 --cpu-seconds 0 > $O/pmc_$N.log 2>&1
   grep -h trace_kernel $O/pmc_$N/*/*counter_collection.csv | awk -F, '{print $(NF-3), $(NF-2)}' | sed 's/"//g'
 done
+cd $R && python3 tools/traffic_json.py $O $WL && cp profiles/traffic_$WL.json $O/
