@@ -558,7 +558,7 @@ extern "C" int srt_gradients(srt_model *m, int64_t n, const double *x, const dou
   else if (m->kind == 3)
     launch_wave_blocks(gradients_kernel<InterpModel, true>, n, 0, (const InterpModel *)m->d_model, (const Common *)m->d_common, (long long)n, (const double *)dx.p, (const double *)dk.p, (const double *)dw.p, del, dout.p);
   else if (m->kind == 4)
-    launch_wave_blocks(gradients_kernel<ScatteredModel, false>, n, 0, (const ScatteredModel *)m->d_model, (const Common *)m->d_common, (long long)n, (const double *)dx.p, (const double *)dk.p, (const double *)dw.p, del, dout.p);
+    launch_wave_blocks(gradients_kernel<ScatteredModel, true>, n, 0, (const ScatteredModel *)m->d_model, (const Common *)m->d_common, (long long)n, (const double *)dx.p, (const double *)dk.p, (const double *)dw.p, del, dout.p);
   else return srt_set_error(SRT_EINVAL, "model kind %d unsupported", m->kind);
   HIP_OK(hipMemcpy(out, dout.p, 14 * n * sizeof(double), hipMemcpyDeviceToHost));
   return SRT_OK;
@@ -577,7 +577,7 @@ extern "C" int srt_rk_step(srt_model *m, int64_t n, const double *args, const do
   else if (m->kind == 3)
     launch_wave_blocks(rkstep_kernel<InterpModel, true>, n, 0, (const InterpModel *)m->d_model, (const Common *)m->d_common, (long long)n, (const double *)da.p, (const double *)dd.p, del, dout.p);
   else if (m->kind == 4)
-    launch_wave_blocks(rkstep_kernel<ScatteredModel, false>, n, 0, (const ScatteredModel *)m->d_model, (const Common *)m->d_common, (long long)n, (const double *)da.p, (const double *)dd.p, del, dout.p);
+    launch_wave_blocks(rkstep_kernel<ScatteredModel, true>, n, 0, (const ScatteredModel *)m->d_model, (const Common *)m->d_common, (long long)n, (const double *)da.p, (const double *)dd.p, del, dout.p);
   else return srt_set_error(SRT_EINVAL, "model kind %d unsupported", m->kind);
   HIP_OK(hipMemcpy(out, dout.p, 21 * n * sizeof(double), hipMemcpyDeviceToHost));
   return SRT_OK;
@@ -639,8 +639,8 @@ extern "C" int srt_trace_batch_device(srt_model *m, const srt_params *p, int64_t
     if (fixed) hipLaunchKernelGGL((trace_kernel<InterpModel, true, true>), dim3((unsigned)grid), dim3(WAVE), 0, st, (const InterpModel *)m->d_model, (const Common *)m->d_common, a);
     else hipLaunchKernelGGL((trace_kernel<InterpModel, false, true>), dim3((unsigned)grid), dim3(WAVE), 0, st, (const InterpModel *)m->d_model, (const Common *)m->d_common, a);
   } else if (m->kind == 4) {
-    if (fixed) hipLaunchKernelGGL((trace_kernel<ScatteredModel, true, false>), dim3((unsigned)grid), dim3(WAVE), 0, st, (const ScatteredModel *)m->d_model, (const Common *)m->d_common, a);
-    else hipLaunchKernelGGL((trace_kernel<ScatteredModel, false, false>), dim3((unsigned)grid), dim3(WAVE), 0, st, (const ScatteredModel *)m->d_model, (const Common *)m->d_common, a);
+    if (fixed) hipLaunchKernelGGL((trace_kernel<ScatteredModel, true, true>), dim3((unsigned)grid), dim3(WAVE), 0, st, (const ScatteredModel *)m->d_model, (const Common *)m->d_common, a);
+    else hipLaunchKernelGGL((trace_kernel<ScatteredModel, false, true>), dim3((unsigned)grid), dim3(WAVE), 0, st, (const ScatteredModel *)m->d_model, (const Common *)m->d_common, a);
   } else {
     return srt_set_error(SRT_EINVAL, "model kind %d unsupported", m->kind);
   }

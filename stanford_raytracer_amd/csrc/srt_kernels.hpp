@@ -87,10 +87,10 @@ __device__ __forceinline__ void rhs_from_plasma(const Common &cm, const double x
 
 template <class M>
 __device__ __forceinline__ void evalrhs(const M &m, const Common &cm, const double x[6], double w, double del,
-                                        double rhs[6], double *lds) {
+                                        double rhs[6], double *lds, bool need = true) {
   double p[7][3], d[3], Ns[7][4], dk[3], dw, B[3];
   stencil_points<7>(x, del, p, d);
-  m.template density_stencil<0>(x, d, nullptr, Ns, lds);
+  m.template density_stencil<0>(x, d, nullptr, Ns, lds, need);
   rhs_from_plasma<7>(cm, x, x + 3, w, d, p, Ns, rhs, dk, dw, B);
 }
 
@@ -117,7 +117,7 @@ __constant__ Tableau TAB_RK4 = {{{0, 0, 0, 0, 0}, {0.5, 0, 0, 0, 0}, {0, 0.5, 0,
 template <class M>
 __device__ __forceinline__ void rk_stages(const M &m, const Common &cm, const Tableau &tab, const double x[6],
                                           double w, double del, double dt, double (&ks)[6][6], double *lds,
-                                          const double *r1 = nullptr) {
+                                          const double *r1 = nullptr, bool need = true) {
 #pragma unroll
   for (int j = 0; j < 6; ++j)
 #pragma unroll
@@ -140,7 +140,7 @@ __device__ __forceinline__ void rk_stages(const M &m, const Common &cm, const Ta
       tmp[c] = x[c] + acc;
     }
     double r[6];
-    evalrhs(m, cm, tmp, w, del, r, lds);
+    evalrhs(m, cm, tmp, w, del, r, lds, need);
 #pragma unroll
     for (int j = 0; j < 6; ++j)
       if (j == s) {
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(64) void trace_kernel(const M *__restrict__ mp, con
   const M &m = *mp;
   const Common &cm = *cp;
   __shared__ __attribute__((aligned(16))) double tile[USE_LDS ? TILE_DOUBLES : 2];
-  double *lds = tile;
+  double *lds = USE_LDS ? tile : nullptr;
   const TraceParams &P = a.p;
   const int lane = threadIdx.x;
   const Tableau &tab = FIXED ? TAB_RK4 : TAB_RKF45;
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(64) void trace_kernel(const M *__restrict__ mp, con
     if (__any(needinit)) {
       double p7[7][3], d7[3], N7[7][4];
       stencil_points<7>(x, P.del, p7, d7);
-      m.template density_stencil<0>(x, d7, nullptr, N7, lds);
+      m.template density_stencil<0>(x, d7, nullptr, N7, lds, needinit);
       if (needinit) {
         double B0[3];
         bfield(cm.fld, x[0], x[1], x[2], B0);
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(64) void trace_kernel(const M *__restrict__ mp, con
     double est1[6], est2[6];
     {
       double ks[6][6];
-      rk_stages(m, cm, tab, x, w, P.del, dt, ks, lds, r1);
+      rk_stages(m, cm, tab, x, w, P.del, dt, ks, lds, r1, active);
       if (FIXED) {
         rk4_combine(x, ks, est2);
 #pragma unroll
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(64) void trace_kernel(const M *__restrict__ mp, con
       pp[NPOST - 1][1] = est1[1];
       pp[NPOST - 1][2] = est1[2];
     }
-    m.template density_stencil<NPOST - 7>(est2, dpost, FIXED ? nullptr : est1, NP_, lds);
+    m.template density_stencil<NPOST - 7>(est2, dpost, FIXED ? nullptr : est1, NP_, lds, active);
     PointState ps2;
 #pragma unroll
     for (int s = 0; s < 4; ++s) ps2.Ns[s] = NP_[0][s];
@@ -557,7 +557,7 @@ __global__ __launch_bounds__(64) void gradients_kernel(const M *__restrict__ mp,
   double st[6] = {x[3 * j], x[3 * j + 1], x[3 * j + 2], k[3 * j], k[3 * j + 1], k[3 * j + 2]};
   double ww = w[j];
   double rhs[6];
-  evalrhs(m, cm, st, ww, del, rhs, tile);
+  evalrhs(m, cm, st, ww, del, rhs, USE_LDS ? tile : nullptr, i < n);
   // recover the gradients themselves: dfdw from a second (cheap) evaluation at the centre
   double p[1][3] = {{st[0], st[1], st[2]}};
   double Ns[1][4];
@@ -596,9 +596,9 @@ __global__ __launch_bounds__(64) void rkstep_kernel(const M *__restrict__ mp, co
   double ww = args[7 * j + 6], dt = dtv[j];
   double ks[6][6];
   double r4[6], o4[6], o5[6];
-  rk_stages(m, cm, TAB_RK4, st, ww, del, dt, ks, tile);
+  rk_stages(m, cm, TAB_RK4, st, ww, del, dt, ks, USE_LDS ? tile : nullptr, nullptr, i < n);
   rk4_combine(st, ks, r4);
-  rk_stages(m, cm, TAB_RKF45, st, ww, del, dt, ks, tile);
+  rk_stages(m, cm, TAB_RKF45, st, ww, del, dt, ks, USE_LDS ? tile : nullptr, nullptr, i < n);
   rk45_combine(st, ks, o4, o5);
   if (i < n) {
     double *o = out + 21 * i;

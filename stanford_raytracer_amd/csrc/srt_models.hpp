@@ -166,7 +166,7 @@ struct NgoModel {
   }
   template <int NE>
   __device__ __forceinline__ void density_stencil(const double c[3], const double d[3], const double *extra,
-                                                  double (&Ns)[7 + NE][4], double *) const {
+                                                  double (&Ns)[7 + NE][4], double *, bool = true) const {
     dens_point(c[0], c[1], c[2], Ns[0]);
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
@@ -309,13 +309,15 @@ struct InterpModel {
     for (int q = 0; q < 8; ++q) ra[q] = base + (unsigned)(((q + lane) & 7) << 4);
   }
   // DMA of one unit into ring buffer J; IMM = byte offset of the unit relative to the addresses in a[]
-  template <int IMM, int J>
+  // AUX = cache policy bits of the load.  (Measured: nt on the species >= 1 units, hoping to keep species 0
+  // resident in L2, made the kernel 9 % slower -- default policy everywhere.)
+  template <int IMM, int J, int AUX = 0>
   __device__ __forceinline__ static void issue_unit(const unsigned long long (&a)[8], double *lds) {
     SRT_AS3 char *ring = (SRT_AS3 char *)lds + TILE_PAD_BYTES;
 #pragma unroll
     for (int t = 0; t < 8; ++t)
       __builtin_amdgcn_global_load_lds((const SRT_AS1 void *)a[t], (SRT_AS3 void *)(ring + (J * UNIT_BYTES + t * 1024 - IMM)),
-                                       16, IMM, 0);
+                                       16, IMM, AUX);
   }
   template <int N>
   __device__ __forceinline__ static void wait_vm() {
@@ -402,7 +404,7 @@ struct InterpModel {
   // retire in issue order, so s_waitcnt vmcnt(24) = "all but the youngest three units have landed").
   template <int NE>
   __device__ __forceinline__ void density_stencil(const double c[3], const double d[3], const double *extra,
-                                                  double (&Ns)[7 + NE][4], double *lds) const {
+                                                  double (&Ns)[7 + NE][4], double *lds, bool = true) const {
     double X[3], Y[3], Z[3], E[3] = {0.0, 0.0, 0.0};
     const int ci = ax.locate(c[0], X[0]), cj = ay.locate(c[1], Y[0]), ck = az.locate(c[2], Z[0]);
     bool same = true;
