@@ -32,7 +32,10 @@ struct ScatteredModel {
       return ((1.0 + eps) / (exp(q * q) - 1.0 + eps)) * win;
     }
     double h = hin / 4.0;
-    return exp(-pow((r + radius * eps) / h, 1.1)) * win;
+    // ((r + radius*eps)/h)**1.1 as x * exp(0.1 ln x): x > 0 always; within ~2 ulp of pow() (the exponent 0.1 ln x is
+    // small, so the logarithm's rounding is damped), at a third of its instruction count
+    double x = (r + radius * eps) / h;
+    return exp(-(x * exp(0.1 * log(x)))) * win;
   }
 
   // visit every sample within `radius` of x (strictly inside, kdtree_mod.f95:171)
@@ -496,8 +499,7 @@ struct ScatteredModel {
       double A[NT], b[J][4];
       int kept = 0;
       bool usemask = true, todo = fit;
-      auto body2 = [&](int i) {
-        const double *q = pts + (size_t)i * 8;
+      auto body2q = [&](const double (&q)[8]) {
         double d0 = q[0] - p[0], d1 = q[1] - p[1], d2 = q[2] - p[2];
         double ss = d0 * d0 + d1 * d1 + d2 * d2;
         if (!(ss < r2)) return; // strictly inside (kdtree_mod.f95:171); only the shared list holds others
@@ -529,13 +531,40 @@ struct ScatteredModel {
             for (int s = 0; s < 4; ++s) b[a][s] = 0.0;
           kept = 0;
         }
-        auto guarded = [&](int i) {
-          if (todo) body2(i);
+        auto guarded = [&](int i) { // (the rare piecewise path)
+          if (todo) {
+            const double *q = pts + (size_t)i * 8;
+            double qq[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) qq[t] = q[t];
+            body2q(qq);
+          }
         };
         int nfin = n_list; // the complete list of pass 1, unless it had to be processed in pieces
         if (partial) scan_rows(p, R, list, nfin, guarded);
+        if (todo) {
+          // walk the list one sample ahead: the next record is in flight while this one is folded in
+          int k = sub;
+          double qn[8];
+          if (k < nfin) {
+            const double *q = pts + (size_t)list[k] * 8;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) qn[t] = q[t];
+          }
 #pragma unroll 1
-        for (int k = sub; k < nfin; k += 8) guarded(list[k]);
+          while (k < nfin) {
+            double qc[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) qc[t] = qn[t];
+            k += 8;
+            if (k < nfin) {
+              const double *q = pts + (size_t)list[k] * 8;
+#pragma unroll
+              for (int t = 0; t < 8; ++t) qn[t] = q[t];
+            }
+            body2q(qc);
+          }
+        }
         if (partial) n_list = nfin;
         const int kept_all = group_sum(kept);
         // threw out too many samples: use them all (:319-323)
