@@ -148,6 +148,21 @@ int srt_write_ray_file(const char *path, int append, int64_t raynum0, int64_t nr
                        const int32_t *stopcond);
 void srt_free(void *p);
 
+/* model-3 grid files, the step before the path: the text format written by
+ * gcpm_dens_model_buildgrid.f95:302-327 and read by interp_dens_model_adapter.f95:58-117, and a binary
+ * side-format ("SRTGRID1": 144-byte header {magic, compder, nspec, nx, ny, nz, bounds[6], qs[4], ms[4]} + the
+ * same value blocks as raw little-endian doubles) for grids whose text takes longer to parse than to trace.
+ * srt_model_create_interp_file() accepts either (detected by the magic).  Pure host code, needs no GPU.
+ *   dims = {compder, nspec, nx, ny, nz}; F[nz][ny][nx][nspec]; derivs = 7 blocks of F's shape, concatenated
+ *   (dfdx dfdy dfdz d2fdxdy d2fdxdz d2fdydz d3fdxdydz), or NULL.  *F / *derivs are malloc'd: srt_free(). */
+int srt_grid_file_read(const char *path, int32_t dims[5], double bounds[6], double qs[4], double ms[4],
+                       double **F, double **derivs);
+int srt_grid_file_write(const char *path, int binary, int nspec, int nx, int ny, int nz,
+                        const double bounds[6], const double *qs, const double *ms, const double *F,
+                        const double *derivs);
+int srt_grid_file_convert(const char *in_text_or_binary, const char *out_binary);
+int srt_grid_file_is_binary(const char *path);
+
 #ifdef __cplusplus
 }
 #endif

@@ -88,6 +88,11 @@ def lib():
                                      dp, dp, ip, ip]
     L.srt_free.argtypes = [vp]
     L.srt_free.restype = None
+    i32p = C.POINTER(C.c_int32)
+    L.srt_grid_file_read.argtypes = [C.c_char_p, i32p, dp, dp, dp, C.POINTER(dp), C.POINTER(dp)]
+    L.srt_grid_file_write.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, dp, dp, dp, dp, dp]
+    L.srt_grid_file_convert.argtypes = [C.c_char_p, C.c_char_p]
+    L.srt_grid_file_is_binary.argtypes = [C.c_char_p]
     _lib = L
     return L
 
@@ -270,3 +275,44 @@ def write_ray_file(path, species, params, w0, rows, nrows, stopcond, raynum0=1, 
     _check(lib().srt_write_ray_file(os.fsencode(path), int(append), raynum0, w0.shape[0], C.byref(params), nspec,
                                     _dp(qs), _dp(ms), _dp(w0), _dp(rows), nrows.ctypes.data_as(ip),
                                     stopcond.ctypes.data_as(ip)))
+
+
+# ---- model-3 grid files: text of the reference's grid builder <-> binary side-format (host code, no GPU) -------
+def read_grid_file(path):
+    """-> dict(F[nz,ny,nx,nspec], bounds[6], qs, ms, derivs = None | [7] arrays of F's shape)."""
+    dims = (C.c_int32 * 5)()
+    bounds, qs, ms = np.zeros(6), np.zeros(4), np.zeros(4)
+    pF, pD = C.POINTER(C.c_double)(), C.POINTER(C.c_double)()
+    _check(lib().srt_grid_file_read(path.encode(), dims, _dp(bounds), _dp(qs), _dp(ms), C.byref(pF), C.byref(pD)))
+    compder, nspec, nx, ny, nz = (int(v) for v in dims)
+    n = nspec * nx * ny * nz
+    try:
+        F = np.ctypeslib.as_array(pF, shape=(n,)).copy().reshape(nz, ny, nx, nspec)
+        derivs = None
+        if compder:
+            derivs = list(np.ctypeslib.as_array(pD, shape=(7 * n,)).copy().reshape(7, nz, ny, nx, nspec))
+    finally:
+        lib().srt_free(pF)
+        if pD:
+            lib().srt_free(pD)
+    return {"F": F, "bounds": bounds, "qs": qs[:nspec], "ms": ms[:nspec], "derivs": derivs}
+
+
+def write_grid_file(path, F, bounds, qs, ms, derivs=None, binary=False):
+    F = _f64(F)
+    nz, ny, nx, nspec = F.shape
+    d = None
+    if derivs is not None:
+        d = _f64(np.stack([np.asarray(a, dtype=np.float64) for a in derivs]), (7, nz, ny, nx, nspec))
+    q4, m4 = np.zeros(4), np.zeros(4)
+    q4[:nspec], m4[:nspec] = qs[:nspec], ms[:nspec]
+    _check(lib().srt_grid_file_write(path.encode(), int(binary), nspec, nx, ny, nz, _dp(_f64(bounds, (6,))), _dp(q4),
+                                     _dp(m4), _dp(F), _dp(d) if d is not None else None))
+
+
+def convert_grid_file(src, dst_binary):
+    _check(lib().srt_grid_file_convert(src.encode(), dst_binary.encode()))
+
+
+def grid_file_is_binary(path):
+    return bool(lib().srt_grid_file_is_binary(path.encode()))

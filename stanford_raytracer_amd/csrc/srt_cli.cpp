@@ -71,8 +71,18 @@ int main(int argc, char **argv) {
          "  model 3: --interp_interpfile --yearday --milliseconds_day --use_tsyganenko=0 --use_igrf=0\n"
          "  model 4: model 3 flags + --scattered_interp_window_scale --scattered_interp_order\n"
          "           --scattered_interp_exact --scattered_interp_local_window_scale\n"
-         "  extra:   --device=N  --first_attempt_policy=0|1  --chunk_rays=N");
+         "  extra:   --device=N  --first_attempt_policy=0|1  --chunk_rays=N\n"
+         "  tools:   --grid2bin_in=<text grid> --grid2bin_out=<binary grid>   (convert and exit; --interp_interpfile\n"
+         "           accepts either form)");
     return 0;
+  }
+  {
+    std::string gin, gout; // model-3 grid: text -> binary side-format (no GPU needed)
+    if (getopt_named("grid2bin_in", gin)) {
+      need(getopt_named("grid2bin_out", gout), "grid2bin_out");
+      CHECK(srt_grid_file_convert(gin.c_str(), gout.c_str()));
+      return 0;
+    }
   }
   srt_params p;
   memset(&p, 0, sizeof p);

@@ -1,4 +1,11 @@
 // srt_host.cpp -- host-side file formats of the drop-in boundary (no device code).
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <thread>
+
 #include "srt_host.hpp"
 
 #include <cmath>
@@ -116,7 +123,8 @@ bool read_newray(const char *path, NgoConfig &c, std::string &err) {
   return true;
 }
 
-bool read_grid_file(const char *path, GridFile &g, std::string &err) {
+// --- the record-by-record reader (exactly the Fortran's READ semantics; slow: one strtod at a time)
+static bool read_grid_file_records(const char *path, GridFile &g, std::string &err) {
   ListReader r(path);
   if (!r.ok()) { err = "cannot open"; return false; }
   double v[8];
@@ -137,6 +145,186 @@ bool read_grid_file(const char *path, GridFile &g, std::string &err) {
       g.derivs[a].resize(n);
       if (r.read((int64_t)n, g.derivs[a].data()) != (int64_t)n) { err = "derivative block truncated"; return false; }
     }
+  return true;
+}
+
+// --- whole-file tokeniser, value block parsed by all host cores (a 256^3 x 4 grid is 67 M numbers, 1.7 GB of text)
+namespace {
+inline bool is_sep(char c) { return c == ' ' || c == '\t' || c == ',' || c == '\r' || c == '\n'; }
+// parse every token of [b, e) as a double ('d' exponents accepted); false on a non-numeric token
+bool parse_tokens(const char *b, const char *e, std::vector<double> &out) {
+  char tok[72];
+  while (b < e) {
+    while (b < e && is_sep(*b)) ++b;
+    if (b >= e) break;
+    int k = 0;
+    while (b < e && !is_sep(*b) && k < 70) {
+      char ch = *b++;
+      tok[k++] = (ch == 'd' || ch == 'D') ? 'e' : ch;
+    }
+    tok[k] = 0;
+    char *endp = nullptr;
+    double v = strtod(tok, &endp);
+    if (endp == tok || *endp) return false;
+    out.push_back(v);
+  }
+  return true;
+}
+struct MappedFile {
+  const char *p = nullptr;
+  size_t n = 0;
+  int fd = -1;
+  explicit MappedFile(const char *path) {
+    fd = open(path, O_RDONLY);
+    if (fd < 0) return;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || st.st_size == 0) return;
+    void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (m == MAP_FAILED) return;
+    p = (const char *)m;
+    n = (size_t)st.st_size;
+  }
+  ~MappedFile() {
+    if (p) munmap((void *)p, n);
+    if (fd >= 0) close(fd);
+  }
+};
+const char GRID_MAGIC[8] = {'S', 'R', 'T', 'G', 'R', 'I', 'D', '1'};
+struct GridBinHeader { // 8 + 5*4 + 4 (pad) + 14*8 = 144 bytes, then F, then 7 derivative blocks if compder == 1
+  char magic[8];
+  int32_t compder, nspec, nx, ny, nz, pad;
+  double bounds[6], qs[4], ms[4];
+};
+} // namespace
+
+bool is_binary_grid(const char *path) {
+  FILE *f = fopen(path, "rb");
+  if (!f) return false;
+  char m[8] = {0};
+  size_t k = fread(m, 1, 8, f);
+  fclose(f);
+  return k == 8 && memcmp(m, GRID_MAGIC, 8) == 0;
+}
+
+static bool read_grid_binary(const char *path, GridFile &g, std::string &err) {
+  MappedFile mf(path);
+  if (!mf.p) { err = "cannot open"; return false; }
+  if (mf.n < sizeof(GridBinHeader)) { err = "binary grid: header truncated"; return false; }
+  GridBinHeader h;
+  memcpy(&h, mf.p, sizeof h);
+  g.compder = h.compder; g.nspec = h.nspec; g.nx = h.nx; g.ny = h.ny; g.nz = h.nz;
+  if (g.nspec < 1 || g.nspec > 4) { err = "nspec must be 1..4"; return false; }
+  if (g.nx < 2 || g.ny < 2 || g.nz < 2) { err = "grid needs >= 2 nodes per axis"; return false; }
+  memcpy(g.bounds, h.bounds, sizeof g.bounds);
+  memcpy(g.qs, h.qs, sizeof g.qs);
+  memcpy(g.ms, h.ms, sizeof g.ms);
+  size_t n = (size_t)g.nx * g.ny * g.nz * g.nspec;
+  g.have_derivs = (g.compder == 1);
+  size_t need = sizeof h + n * sizeof(double) * (g.have_derivs ? 8 : 1);
+  if (mf.n < need) { err = "binary grid: value block truncated"; return false; }
+  const char *q = mf.p + sizeof h;
+  g.F.resize(n);
+  memcpy(g.F.data(), q, n * sizeof(double));
+  if (g.have_derivs)
+    for (int a = 0; a < 7; ++a) {
+      g.derivs[a].resize(n);
+      memcpy(g.derivs[a].data(), q + (size_t)(a + 1) * n * sizeof(double), n * sizeof(double));
+    }
+  return true;
+}
+
+bool write_grid_binary(const char *path, const GridFile &g, std::string &err) {
+  FILE *f = fopen(path, "wb");
+  if (!f) { err = "cannot open for writing"; return false; }
+  GridBinHeader h;
+  memset(&h, 0, sizeof h);
+  memcpy(h.magic, GRID_MAGIC, 8);
+  h.compder = g.have_derivs ? 1 : 0; h.nspec = g.nspec; h.nx = g.nx; h.ny = g.ny; h.nz = g.nz;
+  memcpy(h.bounds, g.bounds, sizeof h.bounds);
+  memcpy(h.qs, g.qs, sizeof h.qs);
+  memcpy(h.ms, g.ms, sizeof h.ms);
+  bool ok = fwrite(&h, sizeof h, 1, f) == 1 && fwrite(g.F.data(), sizeof(double), g.F.size(), f) == g.F.size();
+  if (g.have_derivs)
+    for (int a = 0; a < 7 && ok; ++a) ok = fwrite(g.derivs[a].data(), sizeof(double), g.derivs[a].size(), f) == g.derivs[a].size();
+  ok = (fclose(f) == 0) && ok;
+  if (!ok) err = "write failed";
+  return ok;
+}
+
+bool read_grid_file(const char *path, GridFile &g, std::string &err) {
+  if (is_binary_grid(path)) return read_grid_binary(path, g, err);
+  MappedFile mf(path);
+  if (!mf.p) { err = "cannot open"; return false; }
+  // header: the first four records (sizes; bounds; charges; masses)
+  const char *b = mf.p, *e = mf.p + mf.n;
+  std::vector<double> hv;
+  auto record = [&](int want) -> bool { // one READ: starts on a new record, may continue over following ones
+    size_t got0 = hv.size();
+    while ((int)(hv.size() - got0) < want && b < e) {
+      const char *nl = (const char *)memchr(b, '\n', (size_t)(e - b));
+      const char *le = nl ? nl : e;
+      std::vector<double> t;
+      if (!parse_tokens(b, le, t)) return false;
+      for (double v : t)
+        if ((int)(hv.size() - got0) < want) hv.push_back(v);
+      b = nl ? nl + 1 : e;
+    }
+    return (int)(hv.size() - got0) == want;
+  };
+  if (!record(5)) { err = "size header incomplete"; return false; }
+  g.compder = (int)hv[0]; g.nspec = (int)hv[1]; g.nx = (int)hv[2]; g.ny = (int)hv[3]; g.nz = (int)hv[4];
+  if (g.nspec < 1 || g.nspec > 4) { err = "nspec must be 1..4"; return false; }
+  if (g.nx < 2 || g.ny < 2 || g.nz < 2) { err = "grid needs >= 2 nodes per axis"; return false; }
+  if (!record(6)) { err = "bounds incomplete"; return false; }
+  if (!record(g.nspec)) { err = "charges incomplete"; return false; }
+  if (!record(g.nspec)) { err = "masses incomplete"; return false; }
+  for (int k = 0; k < 6; ++k) g.bounds[k] = hv[5 + k];
+  for (int k = 0; k < g.nspec; ++k) { g.qs[k] = hv[11 + k]; g.ms[k] = hv[11 + g.nspec + k]; }
+  const size_t nnode = (size_t)g.nx * g.ny * g.nz, n = nnode * g.nspec;
+  g.have_derivs = (g.compder == 1);
+  const size_t want = n * (g.have_derivs ? 8 : 1);
+  // value block: cut at record boundaries, one piece per thread
+  unsigned nt = std::thread::hardware_concurrency();
+  nt = nt ? (nt > 32 ? 32 : nt) : 1;
+  if ((size_t)(e - b) < (size_t)nt * 4096) nt = 1;
+  std::vector<const char *> cut(nt + 1);
+  cut[0] = b;
+  cut[nt] = e;
+  for (unsigned t = 1; t < nt; ++t) {
+    const char *c = b + (size_t)(e - b) * t / nt;
+    const char *nl = (const char *)memchr(c, '\n', (size_t)(e - c));
+    cut[t] = nl ? nl + 1 : e;
+  }
+  std::vector<std::vector<double>> part(nt);
+  std::vector<char> good(nt, 1);
+  std::vector<std::thread> th;
+  for (unsigned t = 0; t < nt; ++t)
+    th.emplace_back([&, t] {
+      part[t].reserve((size_t)(cut[t + 1] - cut[t]) / 20 + 16);
+      good[t] = parse_tokens(cut[t], cut[t + 1], part[t]) ? 1 : 0;
+    });
+  for (auto &x : th) x.join();
+  size_t total = 0;
+  bool allgood = true;
+  for (unsigned t = 0; t < nt; ++t) { total += part[t].size(); allgood = allgood && good[t]; }
+  if (!allgood || total != want) {
+    // not the plain one-record-per-node layout (extra fields on a line, a stray token, ...): re-read with the
+    // Fortran's record semantics
+    g = GridFile();
+    return read_grid_file_records(path, g, err);
+  }
+  g.F.resize(n);
+  if (g.have_derivs)
+    for (int a = 0; a < 7; ++a) g.derivs[a].resize(n);
+  size_t pos = 0;
+  for (unsigned t = 0; t < nt; ++t) {
+    for (double v : part[t]) {
+      size_t blk = pos / n, off = pos % n;
+      (blk == 0 ? g.F : g.derivs[blk - 1])[off] = v;
+      ++pos;
+    }
+    std::vector<double>().swap(part[t]);
+  }
   return true;
 }
 
@@ -164,6 +352,88 @@ void format_es24(double v, char out[25]) {
 
 // ================================================================================ C ABI (file I/O)
 extern "C" void srt_free(void *p) { free(p); }
+
+// ---- model-3 grid files: text of gcpm_dens_model_buildgrid.f95:302-327 <-> binary side-format
+extern "C" int srt_grid_file_read(const char *path, int32_t dims[5], double bounds[6], double qs[4], double ms[4],
+                                  double **F, double **derivs) {
+  if (!path || !dims || !bounds || !qs || !ms || !F) return srt_set_error(SRT_EINVAL, "null argument");
+  srt_host::GridFile g;
+  std::string err;
+  if (!srt_host::read_grid_file(path, g, err)) return srt_set_error(SRT_EIO, "%s: %s", path, err.c_str());
+  dims[0] = g.have_derivs ? 1 : 0; dims[1] = g.nspec; dims[2] = g.nx; dims[3] = g.ny; dims[4] = g.nz;
+  memcpy(bounds, g.bounds, 6 * sizeof(double));
+  memcpy(qs, g.qs, 4 * sizeof(double));
+  memcpy(ms, g.ms, 4 * sizeof(double));
+  const size_t n = g.F.size();
+  *F = (double *)malloc(n * sizeof(double));
+  if (!*F) return srt_set_error(SRT_ENOMEM, "grid of %zu values", n);
+  memcpy(*F, g.F.data(), n * sizeof(double));
+  if (derivs) {
+    *derivs = nullptr;
+    if (g.have_derivs) {
+      *derivs = (double *)malloc(7 * n * sizeof(double));
+      if (!*derivs) return srt_set_error(SRT_ENOMEM, "derivative blocks of %zu values", 7 * n);
+      for (int a = 0; a < 7; ++a) memcpy(*derivs + (size_t)a * n, g.derivs[a].data(), n * sizeof(double));
+    }
+  }
+  return SRT_OK;
+}
+
+extern "C" int srt_grid_file_write(const char *path, int binary, int nspec, int nx, int ny, int nz,
+                                   const double bounds[6], const double *qs, const double *ms, const double *F,
+                                   const double *derivs) {
+  if (!path || !bounds || !qs || !ms || !F) return srt_set_error(SRT_EINVAL, "null argument");
+  if (nspec < 1 || nspec > SRT_MAXSPEC || nx < 2 || ny < 2 || nz < 2) return srt_set_error(SRT_EINVAL, "bad grid shape");
+  const size_t n = (size_t)nx * ny * nz * nspec;
+  if (binary) {
+    srt_host::GridFile g;
+    g.nspec = nspec; g.nx = nx; g.ny = ny; g.nz = nz;
+    g.have_derivs = derivs != nullptr;
+    memcpy(g.bounds, bounds, sizeof g.bounds);
+    for (int k = 0; k < nspec; ++k) { g.qs[k] = qs[k]; g.ms[k] = ms[k]; }
+    g.F.assign(F, F + n);
+    if (derivs)
+      for (int a = 0; a < 7; ++a) g.derivs[a].assign(derivs + (size_t)a * n, derivs + (size_t)(a + 1) * n);
+    std::string err;
+    if (!srt_host::write_grid_binary(path, g, err)) return srt_set_error(SRT_EIO, "%s: %s", path, err.c_str());
+    return SRT_OK;
+  }
+  // text: header (5i10), bounds / charges / masses in es24.15e3, then one node per record, then the 7 derivative
+  // blocks (gcpm_dens_model_buildgrid.f95:302-327); values with 17 significant digits so that a round trip is exact
+  FILE *f = fopen(path, "w");
+  if (!f) return srt_set_error(SRT_EIO, "%s: cannot open for writing", path);
+  std::vector<char> big(1 << 22);
+  setvbuf(f, big.data(), _IOFBF, big.size());
+  char num[25];
+  fprintf(f, "%10d%10d%10d%10d%10d\n", derivs ? 1 : 0, nspec, nx, ny, nz);
+  for (int k = 0; k < 6; ++k) { srt_host::format_es24(bounds[k], num); fputs(num, f); }
+  fputc('\n', f);
+  for (int k = 0; k < nspec; ++k) { srt_host::format_es24(qs[k], num); fputs(num, f); }
+  fputc('\n', f);
+  for (int k = 0; k < nspec; ++k) { srt_host::format_es24(ms[k], num); fputs(num, f); }
+  fputc('\n', f);
+  const size_t nnode = n / nspec;
+  for (int blk = 0; blk < (derivs ? 8 : 1); ++blk) {
+    const double *v = blk == 0 ? F : derivs + (size_t)(blk - 1) * n;
+    for (size_t c = 0; c < nnode; ++c) {
+      for (int k = 0; k < nspec; ++k) fprintf(f, k ? " %.17g" : "%.17g", v[c * nspec + k]);
+      fputc('\n', f);
+    }
+  }
+  if (fclose(f) != 0) return srt_set_error(SRT_EIO, "%s: write failed", path);
+  return SRT_OK;
+}
+
+extern "C" int srt_grid_file_convert(const char *in, const char *out_binary) {
+  if (!in || !out_binary) return srt_set_error(SRT_EINVAL, "null argument");
+  srt_host::GridFile g;
+  std::string err;
+  if (!srt_host::read_grid_file(in, g, err)) return srt_set_error(SRT_EIO, "%s: %s", in, err.c_str());
+  if (!srt_host::write_grid_binary(out_binary, g, err)) return srt_set_error(SRT_EIO, "%s: %s", out_binary, err.c_str());
+  return SRT_OK;
+}
+
+extern "C" int srt_grid_file_is_binary(const char *path) { return path && srt_host::is_binary_grid(path) ? 1 : 0; }
 
 extern "C" int64_t srt_read_rays_file(const char *path, double **pos0, double **dir0, double **w0) {
   if (!path || !pos0 || !dir0 || !w0) return srt_set_error(SRT_EINVAL, "null argument");

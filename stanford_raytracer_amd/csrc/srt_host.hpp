@@ -28,7 +28,12 @@ struct GridFile {
   std::vector<double> F;
   std::vector<double> derivs[7];
 };
+// text (parsed by all host cores) or the binary side-format "SRTGRID1" (detected by its magic)
 bool read_grid_file(const char *path, GridFile &g, std::string &err);
+bool is_binary_grid(const char *path);
+// binary side-format: 144-byte header {magic, compder, nspec, nx, ny, nz, bounds[6], qs[4], ms[4]} followed by the
+// value blocks of the text format as raw little-endian doubles in the same order
+bool write_grid_binary(const char *path, const GridFile &g, std::string &err);
 
 // Fortran list-directed numeric reader: a READ starts on a new record and continues over following
 // records until its list is satisfied; blanks and commas separate; 'd' exponents accepted.

@@ -68,3 +68,19 @@ def test_cli_rejects_out_of_scope_requests(tmp_path, cfgfiles):
     assert subprocess.run(base + ["--modelnum=1", "--use_igrf=1"]).returncode == 2
     assert subprocess.run(base + ["--modelnum=2"]).returncode == 2
     assert subprocess.run(base + ["--modelnum=1"]).returncode == 0
+
+
+def test_binary_grid_is_the_same_model(tmp_path, grid16):
+    """a grid converted to the binary side-format by the CLI gives bit-identical plasma parameters to
+    the same grid read from text and to the model built from host arrays."""
+    from stanford_raytracer_amd import api
+
+    F, b, qs, ms = grid16
+    txt, binf = str(tmp_path / "g.txt"), str(tmp_path / "g.bin")
+    wl.write_grid_file(txt, F, b, qs, ms)
+    subprocess.run([os.path.join(BIN, "raytracer"), "--grid2bin_in=%s" % txt, "--grid2bin_out=%s" % binf], check=True)
+    assert api.grid_file_is_binary(binf)
+    pos, _, _ = wl.launch_set(500, 21)
+    ref = api.Model.interp(F, b, qs, ms).plasma_params(pos)
+    for path in (txt, binf):
+        assert np.array_equal(api.Model.interp_file(path).plasma_params(pos), ref)

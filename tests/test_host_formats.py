@@ -79,3 +79,83 @@ def test_launch_set_is_seeded_and_sane():
     assert ang.min() >= 10 - 1e-6 and ang.max() <= 70 + 1e-6
     f = w1 / (2 * np.pi)
     assert f.min() >= 500 and f.max() <= 10000
+
+
+# ---- model-3 grid files: the step before the path ------------------------------------------------
+def _small_grid(with_derivs):
+    rng = np.random.default_rng(11)
+    F = rng.normal(20.0, 3.0, (5, 6, 7, 4))      # [nz, ny, nx, nspec]
+    b = np.array([-3.0e7, 3.0e7, -2.0e7, 2.0e7, -1.0e7, 1.5e7])
+    d = [rng.normal(0.0, 1e-6, F.shape) for _ in range(7)] if with_derivs else None
+    return F, b, d
+
+
+def test_grid_text_reader_matches_the_writers(tmp_path):
+    """The parallel text reader returns exactly what the workload writer (free-format %.17g) and the library's own
+    writer (reference layout: (5i10), es24.15e3 header records, one node per record) put on disk."""
+    for with_derivs in (False, True):
+        F, b, d = _small_grid(with_derivs)
+        p1, p2 = str(tmp_path / "a.txt"), str(tmp_path / "b.txt")
+        wl.write_grid_file(p1, F, b, derivs=d)
+        api.write_grid_file(p2, F, b, wl.QS, wl.MS, derivs=d)
+        first = open(p2).readline()
+        assert first == "%10d%10d%10d%10d%10d\n" % (1 if with_derivs else 0, 4, 7, 6, 5)
+        for path in (p1, p2):
+            assert not api.grid_file_is_binary(path)
+            g = api.read_grid_file(path)
+            assert np.array_equal(g["F"], F) and np.array_equal(g["bounds"], b)
+            assert np.array_equal(g["qs"], wl.QS) and np.array_equal(g["ms"], wl.MS)
+            if with_derivs:
+                assert all(np.array_equal(x, y) for x, y in zip(g["derivs"], d))
+            else:
+                assert g["derivs"] is None
+
+
+def test_grid_text_reader_record_semantics_and_errors(tmp_path):
+    """Fortran 'd' exponents and commas parse; a record with extra fields falls back to the Fortran's record
+    semantics (read(..,*) takes nspec values and skips the rest of the record); truncated files are refused."""
+    F, b, _ = _small_grid(False)
+    lines = open(_write(tmp_path, F, b)).read().splitlines()
+    odd = tmp_path / "odd.txt"
+    body = [ln.replace("e+", "d+").replace("e-", "d-") for ln in lines[4:]]
+    body[3] = body[3].replace(" ", ",") + " 99.0 98.0"       # extra fields on one node's record
+    odd.write_text("\n".join(lines[:4] + body) + "\n")
+    g = api.read_grid_file(str(odd))
+    assert np.array_equal(g["F"], F)
+    cut = tmp_path / "cut.txt"
+    cut.write_text("\n".join(lines[:50]) + "\n")
+    try:
+        api.read_grid_file(str(cut))
+        assert False, "truncated grid accepted"
+    except api.SrtError as e:
+        assert "truncated" in str(e)
+
+
+def _write(tmp_path, F, b):
+    p = str(tmp_path / "g.txt")
+    wl.write_grid_file(p, F, b)
+    return p
+
+
+def test_grid_binary_side_format_round_trip(tmp_path):
+    for with_derivs in (False, True):
+        F, b, d = _small_grid(with_derivs)
+        txt, bin1, bin2 = str(tmp_path / "g.txt"), str(tmp_path / "g1.bin"), str(tmp_path / "g2.bin")
+        wl.write_grid_file(txt, F, b, derivs=d)
+        api.convert_grid_file(txt, bin1)                       # text -> binary
+        api.write_grid_file(bin2, F, b, wl.QS, wl.MS, derivs=d, binary=True)
+        assert open(bin1, "rb").read() == open(bin2, "rb").read()
+        assert api.grid_file_is_binary(bin1)
+        assert os.path.getsize(bin1) == 144 + F.size * 8 * (8 if with_derivs else 1)
+        g = api.read_grid_file(bin1)
+        assert np.array_equal(g["F"], F) and np.array_equal(g["bounds"], b) and np.array_equal(g["ms"], wl.MS)
+        assert (g["derivs"] is None) == (not with_derivs)
+        if with_derivs:
+            assert all(np.array_equal(x, y) for x, y in zip(g["derivs"], d))
+    trunc = tmp_path / "t.bin"
+    trunc.write_bytes(open(bin1, "rb").read()[:1000])
+    try:
+        api.read_grid_file(str(trunc))
+        assert False, "truncated binary grid accepted"
+    except api.SrtError as e:
+        assert "truncated" in str(e)
