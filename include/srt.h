@@ -89,6 +89,17 @@ int srt_model_create_interp(int nspec, int nx, int ny, int nz, const double boun
  * parameters are the --scattered_interp_* flags of raytracer_driver.f95:690-728 */
 int srt_model_create_scattered_file(const char *ptsfile, int yearday, int msec, double window_scale,
                                     int order, int exact, double local_window_scale, srt_model **out);
+/* The step before the path: sample a model's funcPlasmaParams on a regular nx x ny x nz grid in
+ * log space ON THE DEVICE -- gcpm_dens_model_buildgrid.f95:160-300 with any model handle in place of GCPM.
+ * compder = 1 adds the seven explicit finite-difference blocks (d = 1e-3*|pos|, :197-296); compder = 0 leaves the
+ * derivatives to the interp model's own finite differences, as the adapter does.
+ *   srt_build_grid: host outputs F[nz][ny][nx][nspec] and derivs (7 blocks concatenated; may be NULL if !compder),
+ *                   ready for srt_grid_file_write.
+ *   srt_model_create_interp_from_model: the same grid becomes a modelnum=3 model without leaving the device. */
+int srt_build_grid(srt_model *src, int compder, int nx, int ny, int nz, const double bounds[6], double *F,
+                   double *derivs);
+int srt_model_create_interp_from_model(srt_model *src, int compder, int nx, int ny, int nz,
+                                       const double bounds[6], int yearday, int msec, srt_model **out);
 void srt_model_destroy(srt_model *m);
 int srt_model_kind(const srt_model *m);  /* 1, 3 or 4 */
 int srt_model_nspec(const srt_model *m);

@@ -88,6 +88,9 @@ def lib():
                                      dp, dp, ip, ip]
     L.srt_free.argtypes = [vp]
     L.srt_free.restype = None
+    L.srt_build_grid.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, dp, dp, dp]
+    L.srt_model_create_interp_from_model.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, dp, C.c_int, C.c_int,
+                                                     C.POINTER(vp)]
     i32p = C.POINTER(C.c_int32)
     L.srt_grid_file_read.argtypes = [C.c_char_p, i32p, dp, dp, dp, C.POINTER(dp), C.POINTER(dp)]
     L.srt_grid_file_write.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, dp, dp, dp, dp, dp]
@@ -168,6 +171,23 @@ class Model:
         _check(lib().srt_model_create_scattered_file(os.fsencode(ptsfile), yearday, msec, window_scale, order,
                                                      exact, local_window_scale, C.byref(h)))
         return cls(h)
+
+    def build_grid(self, nx, ny, nz, bounds, compder=False):
+        """Sample this model on a regular grid in log space on the device (the reference's grid builder with this
+        model in place of GCPM).  -> F[nz,ny,nx,nspec], derivs (list of 7 arrays or None)."""
+        ns = self.nspec
+        F = np.empty((nz, ny, nx, ns))
+        D = np.empty((7, nz, ny, nx, ns)) if compder else None
+        _check(lib().srt_build_grid(self.h, int(bool(compder)), nx, ny, nz, _dp(_f64(bounds, (6,))), _dp(F),
+                                    _dp(D) if compder else None))
+        return F, (list(D) if compder else None)
+
+    def to_interp(self, nx, ny, nz, bounds, compder=False, yearday=2010001, msec=0):
+        """A modelnum=3 model tabulating this one, built without leaving the device."""
+        h = C.c_void_p()
+        _check(lib().srt_model_create_interp_from_model(self.h, int(bool(compder)), nx, ny, nz,
+                                                        _dp(_f64(bounds, (6,))), yearday, msec, C.byref(h)))
+        return Model(h)
 
     def close(self):
         if self.h:

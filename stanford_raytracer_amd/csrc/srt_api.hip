@@ -314,54 +314,41 @@ __global__ __launch_bounds__(64) void build_coeffs_kernel(GridDims g, ArrPtrs ar
   }
 }
 
-extern "C" int srt_model_create_interp(int nspec, int nx, int ny, int nz, const double bounds[6],
-                                       const double *qs, const double *ms, const double *F,
-                                       const double *const *derivs, int yearday, int msec, srt_model **out) {
-  if (!bounds || !qs || !ms || !F || !out) return srt_set_error(SRT_EINVAL, "null argument");
-  if (nspec < 1 || nspec > SRT_MAXSPEC) return srt_set_error(SRT_EINVAL, "nspec=%d unsupported (1..%d)", nspec, SRT_MAXSPEC);
-  if (nx < 2 || ny < 2 || nz < 2) return srt_set_error(SRT_EINVAL, "grid must have >= 2 nodes per axis");
-  int rc = ensure_init();
-  if (rc) return rc;
+// FD derivatives (unless given) + coefficient expansion + model object, from the 8 arrays already on the device.
+// d_arr[0] = F; d_arr[1..7] = derivative blocks (contents ignored when !have_derivs).  The arrays are freed here.
+static int interp_from_device_arrays(int nspec, int nx, int ny, int nz, const double bounds[6], const double *qs,
+                                     const double *ms, double *d_arr[8], bool have_derivs, int yearday, int msec,
+                                     srt_model **out) {
   const size_t nnode = (size_t)nx * ny * nz, n = nnode * nspec;
   const size_t ncell = (size_t)(nx + 1) * (ny + 1) * (nz + 1);
-  if (ncell >= (size_t)1 << 31) return srt_set_error(SRT_EINVAL, "grid too large");
   GridDims g{nspec, nx, ny, nz};
   // interp_dens_model_adapter.f95:87-89
   double dx = (bounds[1] - bounds[0]) / (nx - 1.0);
   double dy = (bounds[3] - bounds[2]) / (ny - 1.0);
   double dz = (bounds[5] - bounds[4]) / (nz - 1.0);
-  double *d_arr[8] = {nullptr};
   double *d_coef = nullptr;
   auto cleanup = [&]() {
     for (int a = 0; a < 8; ++a)
-      if (d_arr[a]) (void)hipFree(d_arr[a]);
+      if (d_arr[a]) {
+        (void)hipFree(d_arr[a]);
+        d_arr[a] = nullptr;
+      }
   };
-  for (int a = 0; a < 8; ++a) {
-    if (hipMalloc(&d_arr[a], n * sizeof(double)) != hipSuccess) {
-      cleanup();
-      return srt_set_error(SRT_ENOMEM, "hipMalloc of grid arrays failed (%zu bytes each)", n * sizeof(double));
-    }
-  }
-  hipError_t e = hipMemcpy(d_arr[0], F, n * sizeof(double), hipMemcpyHostToDevice);
-  if (e == hipSuccess) {
-    if (derivs) {
-      for (int a = 1; a < 8 && e == hipSuccess; ++a)
-        e = hipMemcpy(d_arr[a], derivs[a - 1], n * sizeof(double), hipMemcpyHostToDevice);
-    } else {
-      for (int a = 1; a < 8 && e == hipSuccess; ++a) e = hipMemset(d_arr[a], 0, n * sizeof(double));
-      int blocks = (int)((n + 255) / 256 < 65535 * 4 ? (n + 255) / 256 : 65535 * 4);
-      auto fd = [&](int src, int dst, int axis, double h) {
-        hipLaunchKernelGGL(fd_axis_kernel, dim3(blocks), dim3(256), 0, 0, g, (const double *)d_arr[src], d_arr[dst], axis, h);
-      };
-      // order and guards of libtricubic.f95:736-790
-      if (nx > 2) fd(0, 1, 0, dx);
-      if (ny > 2) fd(0, 2, 1, dy);
-      if (nz > 2) fd(0, 3, 2, dz);
-      if (nx > 2 && ny > 2) fd(2, 4, 0, dx);
-      if (nx > 2 && nz > 2) fd(3, 5, 0, dx);
-      if (ny > 2 && nz > 2) fd(3, 6, 1, dy);
-      if (nx > 2 && ny > 2 && nz > 2) fd(6, 7, 0, dx);
-    }
+  hipError_t e = hipSuccess;
+  if (!have_derivs) {
+    for (int a = 1; a < 8 && e == hipSuccess; ++a) e = hipMemset(d_arr[a], 0, n * sizeof(double));
+    int blocks = (int)((n + 255) / 256 < 65535 * 4 ? (n + 255) / 256 : 65535 * 4);
+    auto fd = [&](int src, int dst, int axis, double h) {
+      hipLaunchKernelGGL(fd_axis_kernel, dim3(blocks), dim3(256), 0, 0, g, (const double *)d_arr[src], d_arr[dst], axis, h);
+    };
+    // order and guards of libtricubic.f95:736-790
+    if (nx > 2) fd(0, 1, 0, dx);
+    if (ny > 2) fd(0, 2, 1, dy);
+    if (nz > 2) fd(0, 3, 2, dz);
+    if (nx > 2 && ny > 2) fd(2, 4, 0, dx);
+    if (nx > 2 && nz > 2) fd(3, 5, 0, dx);
+    if (ny > 2 && nz > 2) fd(3, 6, 1, dy);
+    if (nx > 2 && ny > 2 && nz > 2) fd(6, 7, 0, dx);
   }
   if (e == hipSuccess) e = hipMalloc(&d_coef, ncell * nspec * 64 * sizeof(double));
   if (e != hipSuccess) {
@@ -393,13 +380,213 @@ extern "C" int srt_model_create_interp(int nspec, int nx, int ny, int nz, const 
   m->interp.ay = Axis{bounds[2], dy, 1.0 / dy, ny};
   m->interp.az = Axis{bounds[4], dz, 1.0 / dz, nz};
   fill_common(m->cm, nspec, qs, ms, yearday, msec);
-  rc = model_finish(m);
+  int rc = model_finish(m);
   if (rc) {
     srt_model_destroy(m);
     return rc;
   }
   *out = m;
   return SRT_OK;
+}
+
+static int alloc_grid_arrays(size_t n, double *d_arr[8]) {
+  for (int a = 0; a < 8; ++a) d_arr[a] = nullptr;
+  for (int a = 0; a < 8; ++a) {
+    if (hipMalloc(&d_arr[a], n * sizeof(double)) != hipSuccess) {
+      for (int b = 0; b < a; ++b) (void)hipFree(d_arr[b]);
+      return srt_set_error(SRT_ENOMEM, "hipMalloc of grid arrays failed (%zu bytes each)", n * sizeof(double));
+    }
+  }
+  return SRT_OK;
+}
+
+extern "C" int srt_model_create_interp(int nspec, int nx, int ny, int nz, const double bounds[6],
+                                       const double *qs, const double *ms, const double *F,
+                                       const double *const *derivs, int yearday, int msec, srt_model **out) {
+  if (!bounds || !qs || !ms || !F || !out) return srt_set_error(SRT_EINVAL, "null argument");
+  if (nspec < 1 || nspec > SRT_MAXSPEC) return srt_set_error(SRT_EINVAL, "nspec=%d unsupported (1..%d)", nspec, SRT_MAXSPEC);
+  if (nx < 2 || ny < 2 || nz < 2) return srt_set_error(SRT_EINVAL, "grid must have >= 2 nodes per axis");
+  int rc = ensure_init();
+  if (rc) return rc;
+  const size_t n = (size_t)nx * ny * nz * nspec;
+  if ((size_t)(nx + 1) * (ny + 1) * (nz + 1) >= (size_t)1 << 31) return srt_set_error(SRT_EINVAL, "grid too large");
+  double *d_arr[8];
+  rc = alloc_grid_arrays(n, d_arr);
+  if (rc) return rc;
+  hipError_t e = hipMemcpy(d_arr[0], F, n * sizeof(double), hipMemcpyHostToDevice);
+  if (derivs)
+    for (int a = 1; a < 8 && e == hipSuccess; ++a)
+      e = hipMemcpy(d_arr[a], derivs[a - 1], n * sizeof(double), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    for (int a = 0; a < 8; ++a) (void)hipFree(d_arr[a]);
+    return srt_set_error(SRT_EDEVICE, "grid upload: %s", hipGetErrorString(e));
+  }
+  return interp_from_device_arrays(nspec, nx, ny, nz, bounds, qs, ms, d_arr, derivs != nullptr, yearday, msec, out);
+}
+
+// ---- the step before the path: sample a model on a regular grid, in log space, on the device ----
+// gcpm_dens_model_buildgrid.f95:160-300 with any in-scope model in place of GCPM: node coordinates
+// (/ (ind) /)*del + min (:163-179), f = log(Ns) (:212-214), and, for compder = 1, the seven explicit
+// finite-difference blocks with d = 1e-3*|pos| (:197-201, :219-296) in the reference's own order of operations.
+struct SampleArgs {
+  double min[3], del[3];
+  double *a[8];
+  long long nnode;
+  int compder;
+};
+template <class M, bool USE_LDS>
+__global__ __launch_bounds__(64) void sample_grid_kernel(const M *__restrict__ mp, GridDims g, SampleArgs A) {
+  const M &m = *mp;
+  __shared__ __attribute__((aligned(16))) double tile[USE_LDS ? TILE_DOUBLES : 2];
+  const long long id = (long long)blockIdx.x * WAVE + threadIdx.x;
+  const bool live = id < A.nnode;
+  const long long node = live ? id : A.nnode - 1; // every lane takes part in the (cooperative) lookups
+  const int i = (int)(node % g.nx), j = (int)((node / g.nx) % g.ny), k = (int)(node / ((long long)g.nx * g.ny));
+  double pos[3];
+  {
+#pragma clang fp contract(off)
+    double px = (double)i * A.del[0], py = (double)j * A.del[1], pz = (double)k * A.del[2];
+    pos[0] = px + A.min[0];
+    pos[1] = py + A.min[1];
+    pos[2] = pz + A.min[2];
+  }
+  double d = 1.0e-3 * sqrt(pos[0] * pos[0] + pos[1] * pos[1] + pos[2] * pos[2]);
+  if (d == 0.0) d = 1.0e-3;
+  auto lnN = [&](double sx, double sy, double sz, double (&L)[4]) { // log(Ns) at (pos + sx*dx) + sy*dy) + sz*dz
+    double p[1][3] = {{(pos[0] + sx * d) + 0.0, (pos[1] + 0.0) + sy * d, ((pos[2] + 0.0) + 0.0) + sz * d}};
+    double Ns[1][4];
+    m.template density<1>(p, Ns, tile);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) L[s] = log(Ns[0][s]);
+  };
+  auto put = [&](int blk, const double (&v)[4]) {
+    if (live)
+      for (int s = 0; s < g.nspec; ++s) A.a[blk][(size_t)node * g.nspec + s] = v[s];
+  };
+  double f[4], t[4], u[4];
+  lnN(0, 0, 0, f);
+  put(0, f);
+  if (!A.compder) return;
+  // first derivatives: tmp = log(N+) ; tmp = tmp - log(N-) ; tmp = tmp/d/2
+  for (int ax = 0; ax < 3; ++ax) {
+    lnN(ax == 0, ax == 1, ax == 2, t);
+    lnN(-(ax == 0), -(ax == 1), -(ax == 2), u);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) t[s] = (t[s] - u[s]) / d / 2.0;
+    put(1 + ax, t);
+  }
+  // mixed second derivatives: (+,+) - (-,+) - (+,-) + (-,-) ; /d/d/4        pairs (x,y) (x,z) (y,z)
+  for (int pr = 0; pr < 3; ++pr) {
+    const int a0 = pr == 2 ? 1 : 0, a1 = pr == 0 ? 1 : 2;
+    double sg[3];
+    auto at = [&](double s0, double s1, double (&L)[4]) {
+      sg[0] = sg[1] = sg[2] = 0.0;
+      sg[a0] = s0;
+      sg[a1] = s1;
+      lnN(sg[0], sg[1], sg[2], L);
+    };
+    at(1, 1, t);
+    at(-1, 1, u);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) t[s] = t[s] - u[s];
+    at(1, -1, u);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) t[s] = t[s] - u[s];
+    at(-1, -1, u);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) t[s] = (t[s] + u[s]) / d / d / 4.0;
+    put(4 + pr, t);
+  }
+  // third derivative: +++ -(-++) -(+-+) +(--+) -(++-) +(-+-) +(+--) -(---) ; /d/d/d/8
+  {
+    const double sx[8] = {1, -1, 1, -1, 1, -1, 1, -1}, sy[8] = {1, 1, -1, -1, 1, 1, -1, -1}, sz[8] = {1, 1, 1, 1, -1, -1, -1, -1};
+    const double sign[8] = {1, -1, -1, 1, -1, 1, 1, -1};
+    lnN(sx[0], sy[0], sz[0], t);
+    for (int q = 1; q < 8; ++q) {
+      lnN(sx[q], sy[q], sz[q], u);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) t[s] = sign[q] > 0 ? t[s] + u[s] : t[s] - u[s];
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) t[s] = t[s] / d / d / d / 8.0;
+    put(7, t);
+  }
+}
+
+// fills d_arr[0] (and d_arr[1..7] when compder) on the device
+static int sample_model_on_grid(srt_model *src, int compder, int nx, int ny, int nz, const double bounds[6],
+                                double *d_arr[8]) {
+  GridDims g{src->nspec, nx, ny, nz};
+  SampleArgs A;
+  // gcpm_dens_model_buildgrid.f95:161-163
+  A.del[0] = (bounds[1] - bounds[0]) / (nx - 1.0);
+  A.del[1] = (bounds[3] - bounds[2]) / (ny - 1.0);
+  A.del[2] = (bounds[5] - bounds[4]) / (nz - 1.0);
+  A.min[0] = bounds[0];
+  A.min[1] = bounds[2];
+  A.min[2] = bounds[4];
+  for (int a = 0; a < 8; ++a) A.a[a] = d_arr[a];
+  A.nnode = (long long)nx * ny * nz;
+  A.compder = compder;
+  const unsigned blocks = (unsigned)((A.nnode + WAVE - 1) / WAVE);
+  if (src->kind == 1)
+    hipLaunchKernelGGL((sample_grid_kernel<NgoModel, false>), dim3(blocks), dim3(WAVE), 0, 0, (const NgoModel *)src->d_model, g, A);
+  else if (src->kind == 3)
+    hipLaunchKernelGGL((sample_grid_kernel<InterpModel, true>), dim3(blocks), dim3(WAVE), 0, 0, (const InterpModel *)src->d_model, g, A);
+  else
+    hipLaunchKernelGGL((sample_grid_kernel<ScatteredModel, false>), dim3(blocks), dim3(WAVE), 0, 0, (const ScatteredModel *)src->d_model, g, A);
+  hipError_t e = hipDeviceSynchronize();
+  if (e != hipSuccess) return srt_set_error(SRT_EDEVICE, "grid sampling failed: %s", hipGetErrorString(e));
+  return SRT_OK;
+}
+
+static int check_grid_request(srt_model *src, int nx, int ny, int nz, const double bounds[6]) {
+  if (!src || !bounds) return srt_set_error(SRT_EINVAL, "null argument");
+  if (nx < 2 || ny < 2 || nz < 2) return srt_set_error(SRT_EINVAL, "grid must have >= 2 nodes per axis");
+  if ((size_t)(nx + 1) * (ny + 1) * (nz + 1) >= (size_t)1 << 31) return srt_set_error(SRT_EINVAL, "grid too large");
+  if (!(bounds[1] > bounds[0]) || !(bounds[3] > bounds[2]) || !(bounds[5] > bounds[4])) return srt_set_error(SRT_EINVAL, "empty bounds");
+  return ensure_init();
+}
+
+extern "C" int srt_build_grid(srt_model *src, int compder, int nx, int ny, int nz, const double bounds[6], double *F,
+                              double *derivs) {
+  int rc = check_grid_request(src, nx, ny, nz, bounds);
+  if (rc) return rc;
+  if (!F || (compder && !derivs)) return srt_set_error(SRT_EINVAL, "null output");
+  const size_t n = (size_t)nx * ny * nz * src->nspec;
+  double *d_arr[8];
+  rc = alloc_grid_arrays(n, d_arr);
+  if (rc) return rc;
+  rc = sample_model_on_grid(src, compder ? 1 : 0, nx, ny, nz, bounds, d_arr);
+  hipError_t e = hipSuccess;
+  if (!rc) {
+    e = hipMemcpy(F, d_arr[0], n * sizeof(double), hipMemcpyDeviceToHost);
+    if (compder)
+      for (int a = 1; a < 8 && e == hipSuccess; ++a)
+        e = hipMemcpy(derivs + (size_t)(a - 1) * n, d_arr[a], n * sizeof(double), hipMemcpyDeviceToHost);
+  }
+  for (int a = 0; a < 8; ++a) (void)hipFree(d_arr[a]);
+  if (rc) return rc;
+  if (e != hipSuccess) return srt_set_error(SRT_EDEVICE, "grid download: %s", hipGetErrorString(e));
+  return SRT_OK;
+}
+
+extern "C" int srt_model_create_interp_from_model(srt_model *src, int compder, int nx, int ny, int nz,
+                                                  const double bounds[6], int yearday, int msec, srt_model **out) {
+  int rc = check_grid_request(src, nx, ny, nz, bounds);
+  if (rc) return rc;
+  if (!out) return srt_set_error(SRT_EINVAL, "null argument");
+  const size_t n = (size_t)nx * ny * nz * src->nspec;
+  double *d_arr[8];
+  rc = alloc_grid_arrays(n, d_arr);
+  if (rc) return rc;
+  rc = sample_model_on_grid(src, compder ? 1 : 0, nx, ny, nz, bounds, d_arr);
+  if (rc) {
+    for (int a = 0; a < 8; ++a) (void)hipFree(d_arr[a]);
+    return rc;
+  }
+  return interp_from_device_arrays(src->nspec, nx, ny, nz, bounds, src->cm.sp.q, src->cm.sp.m, d_arr, compder != 0,
+                                   yearday, msec, out);
 }
 
 extern "C" int srt_model_create_interp_file(const char *gridfile, int yearday, int msec, srt_model **out) {
