@@ -398,8 +398,9 @@ extern "C" int srt_grid_file_write(const char *path, int binary, int nspec, int 
     if (!srt_host::write_grid_binary(path, g, err)) return srt_set_error(SRT_EIO, "%s: %s", path, err.c_str());
     return SRT_OK;
   }
-  // text: header (5i10), bounds / charges / masses in es24.15e3, then one node per record, then the 7 derivative
-  // blocks (gcpm_dens_model_buildgrid.f95:302-327); values with 17 significant digits so that a round trip is exact
+  // text, byte for byte what gcpm_dens_model_buildgrid.f95:302-327 writes: (5i10); (6es24.15e3); charges; masses;
+  // then every value on its own record in es24.15e3 (16 significant digits -- the format's, not ours: use the
+  // binary form where the last bit matters)
   FILE *f = fopen(path, "w");
   if (!f) return srt_set_error(SRT_EIO, "%s: cannot open for writing", path);
   std::vector<char> big(1 << 22);
@@ -412,12 +413,12 @@ extern "C" int srt_grid_file_write(const char *path, int binary, int nspec, int 
   fputc('\n', f);
   for (int k = 0; k < nspec; ++k) { srt_host::format_es24(ms[k], num); fputs(num, f); }
   fputc('\n', f);
-  const size_t nnode = n / nspec;
   for (int blk = 0; blk < (derivs ? 8 : 1); ++blk) {
     const double *v = blk == 0 ? F : derivs + (size_t)(blk - 1) * n;
-    for (size_t c = 0; c < nnode; ++c) {
-      for (int k = 0; k < nspec; ++k) fprintf(f, k ? " %.17g" : "%.17g", v[c * nspec + k]);
-      fputc('\n', f);
+    for (size_t c = 0; c < n; ++c) {
+      srt_host::format_es24(v[c], num);
+      num[24] = '\n';
+      fwrite(num, 1, 25, f);
     }
   }
   if (fclose(f) != 0) return srt_set_error(SRT_EIO, "%s: write failed", path);

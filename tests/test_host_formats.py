@@ -91,22 +91,27 @@ def _small_grid(with_derivs):
 
 
 def test_grid_text_reader_matches_the_writers(tmp_path):
-    """The parallel text reader returns exactly what the workload writer (free-format %.17g) and the library's own
-    writer (reference layout: (5i10), es24.15e3 header records, one node per record) put on disk."""
+    """The parallel text reader returns exactly what the workload writer (free-format %.17g, one node per record)
+    put on disk, and the library's own text writer produces the reference's layout: (5i10), es24.15e3 header
+    records, one VALUE per record in es24.15e3 (16 significant digits)."""
     for with_derivs in (False, True):
         F, b, d = _small_grid(with_derivs)
         p1, p2 = str(tmp_path / "a.txt"), str(tmp_path / "b.txt")
         wl.write_grid_file(p1, F, b, derivs=d)
         api.write_grid_file(p2, F, b, wl.QS, wl.MS, derivs=d)
-        first = open(p2).readline()
-        assert first == "%10d%10d%10d%10d%10d\n" % (1 if with_derivs else 0, 4, 7, 6, 5)
-        for path in (p1, p2):
+        lines = open(p2).read().split("\n")
+        assert lines[0] == "%10d%10d%10d%10d%10d" % (1 if with_derivs else 0, 4, 7, 6, 5)
+        assert len(lines[1]) == 6 * 24 and len(lines[2]) == 4 * 24 and all(len(x) == 24 for x in lines[4:-1])
+        assert len(lines) - 5 == F.size * (8 if with_derivs else 1)
+        assert lines[4] == "%24s" % ("%.15E" % F.flat[0]).replace("E+", "E+0").replace("E-", "E-0")
+        for path, exact in ((p1, True), (p2, False)):
             assert not api.grid_file_is_binary(path)
             g = api.read_grid_file(path)
-            assert np.array_equal(g["F"], F) and np.array_equal(g["bounds"], b)
-            assert np.array_equal(g["qs"], wl.QS) and np.array_equal(g["ms"], wl.MS)
+            same = np.array_equal if exact else (lambda x, y: np.allclose(x, y, rtol=6e-16, atol=0))
+            assert same(g["F"], F) and same(g["bounds"], b)
+            assert same(g["qs"], wl.QS) and same(g["ms"], wl.MS)
             if with_derivs:
-                assert all(np.array_equal(x, y) for x, y in zip(g["derivs"], d))
+                assert all(same(x, y) for x, y in zip(g["derivs"], d))
             else:
                 assert g["derivs"] is None
 
