@@ -236,6 +236,8 @@ def main():
                        "model_setup_s": setup_s, "model_device_GB": model.device_bytes / 1e9},
         }
         out["cpu_baseline"] = cpu_baseline(args, kind, p, wl, pos0, dir0, w0, grid_n) if (args.cpu_seconds > 0 and world == 1) else None
+        # the real reference (Fortran, one core -- its only mode), when its prebuilt harness travelled with the repo
+        out["cpu_reference"] = cpu_reference(args, kind, p, wl, pos0, dir0, w0) if (args.cpu_seconds > 0 and world == 1) else None
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
@@ -277,6 +279,48 @@ def cpu_baseline(args, kind, p, wl, pos0, dir0, w0, grid_n):
     return {"value": s1 / dt1, "unit": "accepted ray-steps/s", "cores": cores, "kind": "port",
             "sample": "first %d rays of the same launch set, same model and integrator parameters, %d accepted steps in %.1f s "
                       "(oracle/srt_oracle.c, pthreads over rays; model setup %.1f s excluded)" % (n1, s1, dt1, setup)}
+
+
+def cpu_reference(args, kind, p, wl, pos0, dir0, w0):
+    """The reference itself -- oracle/_ref/ref_harness = rareid2/Stanford_Raytracer's own raytracer_run + adapters
+    compiled with flang (oracle/build_ref.py), single-threaded as the reference is -- timed around its ray loop on
+    the first rays of the same launch set.  The interp workload is served from a 64^3 text grid of the same analytic
+    plasmasphere: the Fortran adapter needs minutes to parse the 1.7 GB text form of the 256^3 grid (its per-step
+    cost does not depend on the grid size beyond the O(nx) cell search)."""
+    try:
+        from oracle import refharness
+    except Exception as e:  # pragma: no cover
+        return {"error": "refharness unavailable: %s" % e}
+    if not refharness.available() or kind == "scattered":
+        return None
+    td = tempfile.mkdtemp()
+    if kind == "interp":
+        gn = 64
+        F, bounds = wl.make_grid(gn, half_width=10.0 * wl.R_E)
+        gfile = os.path.join(td, "grid64.txt")
+        wl.write_grid_file(gfile, F, bounds)
+        model = {"kind": 3, "file": gfile}
+        note = "interp model on a %d^3 text grid of the same plasmasphere" % gn
+    else:
+        cfg = os.path.join(td, "newray.in")
+        with open(cfg, "w") as f:
+            f.write(wl.NEWRAY_PLASMAPAUSE)
+        model = {"kind": 1, "file": cfg}
+        note = "ngo model"
+    kw = dict(dt0=p.dt0, dtmax=p.dtmax, tmax=p.tmax, maxerr=p.maxerr, minalt=p.minalt, maxsteps=p.maxsteps,
+              root=p.root, fixedstep=p.fixedstep)
+    kw["del"] = p.del_
+    budget = min(args.cpu_seconds, 12.0)
+    n0 = min(8, len(w0))
+    rays = np.concatenate([pos0, dir0, w0[:, None]], axis=1)
+    _, t0 = refharness.run_rays(model, rays[:n0], **kw)
+    if not t0 or t0["seconds"] <= 0:
+        return {"error": "reference harness gave no timing"}
+    n1 = int(min(len(w0), max(n0, n0 * budget / max(t0["seconds"], 1e-3))))
+    _, t1 = refharness.run_rays(model, rays[:n1], **kw)
+    return {"value": t1["steps"] / t1["seconds"], "unit": "accepted ray-steps/s", "cores": 1, "kind": "reference",
+            "sample": "first %d rays of the same launch set, same integrator parameters, %s: %d accepted steps in %.1f s "
+                      "inside the reference's ray loop (oracle/_ref/ref_harness, flang -O3)" % (n1, note, t1["steps"], t1["seconds"])}
 
 
 if __name__ == "__main__":
