@@ -52,6 +52,9 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline sample duration (0=skip)")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--refill", type=int, default=0)
+    ap.add_argument("--ray-order", type=int, default=1, choices=[0, 1],
+                    help="srt_params.ray_order: 1 = the library works through the launch set sorted by launch cell "
+                         "(device sort inside the timed region; SURVEY 8d allows this permutation), 0 = as given")
     return ap.parse_args()
 
 
@@ -131,6 +134,7 @@ def main():
         wname = "%d rays/GPU, ngo_dens_model, dipole B, adaptive RK45" % nrays
 
     pos0, dir0, w0 = wl.launch_set(nrays, seed + 1000 * rank)
+    p.ray_order = args.ray_order
     slots = api.lib().srt_rows_per_ray(p)
     d_pos = torch.from_numpy(np.ascontiguousarray(pos0.T)).to(dev)  # SoA [3][n]
     d_dir = torch.from_numpy(np.ascontiguousarray(dir0.T)).to(dev)
@@ -217,6 +221,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": wname, "rays_per_gpu": nrays, "grid": grid_n, "maxsteps": p.maxsteps,
                        "outputper": p.outputper, "integrator": "rkf45 adaptive", "parallelism": "rays sharded x%d" % world,
+                       "ray_order": "launch-cell Morton order, sorted on the device inside the timed region" if (args.ray_order and kind == "interp") else "as given",
                        "gather": bool(dist is not None and not args.no_gather)},
             # achieved/frac: ALGORITHMIC bytes (every lookup counted at 2 KiB) / kernel time -- exceeds the
             # HBM peak because consecutive lookups of a ray re-read the same block.  traffic: fabric-side bytes per

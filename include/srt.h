@@ -63,6 +63,10 @@ typedef struct srt_params {
   int32_t first_attempt_policy; /* 0: NaN error term => accept, no growth (flang; SURVEY A-1)
                                    1: error from the k term alone (gfortran<=8) */
   int32_t refill_threshold;     /* free lanes per wave before new rays are claimed (0 = default) */
+  int32_t ray_order;            /* order in which the launch set is WORKED ON (results and their order are unchanged):
+                                   0 = as given; 1 = sorted on the device by the Morton code of the launch cell, so
+                                   that the lanes of a wave start in neighbouring cells of the interp grid and share
+                                   coefficient lines (SURVEY.md 8d allows this input permutation; other models ignore it) */
 } srt_params;
 
 typedef struct srt_model srt_model; /* opaque; owns device copies of all model data */

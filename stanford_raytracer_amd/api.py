@@ -26,13 +26,13 @@ class Params(C.Structure):
     _fields_ = [("dt0", C.c_double), ("dtmax", C.c_double), ("tmax", C.c_double), ("maxerr", C.c_double),
                 ("minalt", C.c_double), ("del_", C.c_double), ("maxsteps", C.c_int32), ("root", C.c_int32),
                 ("fixedstep", C.c_int32), ("outputper", C.c_int32), ("first_attempt_policy", C.c_int32),
-                ("refill_threshold", C.c_int32)]
+                ("refill_threshold", C.c_int32), ("ray_order", C.c_int32)]
 
 
 def make_params(dt0=1e-3, dtmax=0.1, tmax=1.0, maxerr=5e-4, minalt=6371.2e3 + 100e3, del_=1e-6, maxsteps=2000,
-                root=2, fixedstep=0, outputper=1, first_attempt_policy=0, refill_threshold=0):
+                root=2, fixedstep=0, outputper=1, first_attempt_policy=0, refill_threshold=0, ray_order=0):
     return Params(dt0, dtmax, tmax, maxerr, minalt, del_, maxsteps, root, fixedstep, outputper,
-                  first_attempt_policy, refill_threshold)
+                  first_attempt_policy, refill_threshold, ray_order)
 
 
 _lib = None

@@ -15,6 +15,7 @@
 #include "srt_host.hpp"
 #include "srt_kernels.hpp"
 #include "srt_scattered.hpp"
+#include <hipcub/hipcub.hpp>
 #include "tricubic_matrix.h"
 
 using namespace srt;
@@ -81,6 +82,11 @@ struct srt_model {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
   int cu_count = 256;
+  // scratch of the ray_order option (grow-only): keys in/out, ids in/out, radix-sort workspace
+  unsigned *d_keys[2] = {nullptr, nullptr};
+  int *d_ids[2] = {nullptr, nullptr};
+  void *d_sorttmp = nullptr;
+  size_t sort_cap = 0, sorttmp_bytes = 0;
 };
 
 static void fill_common(Common &cm, int nspec, const double *qs, const double *ms, int yearday, int msec) {
@@ -132,6 +138,11 @@ extern "C" void srt_model_destroy(srt_model *m) {
   if (m->d_pts) (void)hipFree(m->d_pts);
   if (m->d_cells) (void)hipFree(m->d_cells);
   if (m->d_model) (void)hipFree(m->d_model);
+  for (int k = 0; k < 2; ++k) {
+    if (m->d_keys[k]) (void)hipFree(m->d_keys[k]);
+    if (m->d_ids[k]) (void)hipFree(m->d_ids[k]);
+  }
+  if (m->d_sorttmp) (void)hipFree(m->d_sorttmp);
   if (m->d_common) (void)hipFree(m->d_common);
   if (m->ev0) (void)hipEventDestroy(m->ev0);
   if (m->ev1) (void)hipEventDestroy(m->ev1);
@@ -782,7 +793,29 @@ static int check_params(const srt_params *p) {
   if (p->maxsteps < 1) return srt_set_error(SRT_EINVAL, "maxsteps must be >= 1");
   if (p->root != 1 && p->root != 2) return srt_set_error(SRT_EINVAL, "root must be 1 or 2");
   if (!(p->del > 0.0)) return srt_set_error(SRT_EINVAL, "del must be > 0");
+  if (p->ray_order != 0 && p->ray_order != 1) return srt_set_error(SRT_EINVAL, "ray_order must be 0 or 1");
   return SRT_OK;
+}
+
+// ray_order = 1: Morton code of the launch cell (9 bits per axis) per ray
+__device__ __forceinline__ unsigned spread3(unsigned v) { // 0b abc -> 0b a00b00c
+  v &= 0x3ffu;
+  v = (v | (v << 16)) & 0x030000ffu;
+  v = (v | (v << 8)) & 0x0300f00fu;
+  v = (v | (v << 4)) & 0x030c30c3u;
+  v = (v | (v << 2)) & 0x09249249u;
+  return v;
+}
+__global__ void ray_keys_kernel(const InterpModel *mp, const double *pos0 /* SoA [3][n] */, long long n, unsigned *keys,
+                                int *ids) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const InterpModel &m = *mp;
+  double xl;
+  unsigned ci = (unsigned)m.ax.locate(pos0[i], xl), cj = (unsigned)m.ay.locate(pos0[n + i], xl),
+           ck = (unsigned)m.az.locate(pos0[2 * n + i], xl);
+  keys[i] = spread3(ci) | (spread3(cj) << 1) | (spread3(ck) << 2);
+  ids[i] = (int)i;
 }
 
 extern "C" int srt_trace_batch_device(srt_model *m, const srt_params *p, int64_t nrays, const double *d_pos0,
@@ -810,6 +843,7 @@ extern "C" int srt_trace_batch_device(srt_model *m, const srt_params *p, int64_t
   a.p.first_attempt_policy = p->first_attempt_policy;
   a.p.refill_threshold = p->refill_threshold;
   a.p.slots = srt_rows_per_ray(p);
+  a.order = nullptr;
   HIP_OK(hipMemsetAsync(d_counters, 0, 4 * sizeof(int64_t), st));
   // persistent grid: enough one-wave blocks to fill the chip, never more than the rays need
   long long want = (nrays + WAVE - 1) / WAVE;
@@ -818,6 +852,38 @@ extern "C" int srt_trace_batch_device(srt_model *m, const srt_params *p, int64_t
   if (grid > want) grid = want;
   if (grid < 1) grid = 1;
   HIP_OK(hipEventRecord(m->ev0, st));
+  if (p->ray_order == 1 && m->kind == 3 && nrays > WAVE && nrays < (1ll << 31) && m->interp.ax.n < 1023 &&
+      m->interp.ay.n < 1023 && m->interp.az.n < 1023) {
+    // work through the launch set in the order of the rays' launch cells (inside the timed region)
+    if ((size_t)nrays > m->sort_cap) {
+      for (int k = 0; k < 2; ++k) {
+        if (m->d_keys[k]) (void)hipFree(m->d_keys[k]);
+        if (m->d_ids[k]) (void)hipFree(m->d_ids[k]);
+        m->d_keys[k] = nullptr;
+        m->d_ids[k] = nullptr;
+      }
+      m->sort_cap = 0;
+      for (int k = 0; k < 2; ++k) {
+        HIP_OK(hipMalloc(&m->d_keys[k], (size_t)nrays * sizeof(unsigned)));
+        HIP_OK(hipMalloc(&m->d_ids[k], (size_t)nrays * sizeof(int)));
+      }
+      m->sort_cap = (size_t)nrays;
+    }
+    size_t need = 0;
+    HIP_OK(hipcub::DeviceRadixSort::SortPairs(nullptr, need, m->d_keys[0], m->d_keys[1], m->d_ids[0], m->d_ids[1], (int)nrays, 0, 30, st));
+    if (need > m->sorttmp_bytes) {
+      if (m->d_sorttmp) (void)hipFree(m->d_sorttmp);
+      m->d_sorttmp = nullptr;
+      m->sorttmp_bytes = 0;
+      HIP_OK(hipMalloc(&m->d_sorttmp, need));
+      m->sorttmp_bytes = need;
+    }
+    hipLaunchKernelGGL(ray_keys_kernel, dim3((unsigned)((nrays + 255) / 256)), dim3(256), 0, st, (const InterpModel *)m->d_model,
+                       d_pos0, (long long)nrays, m->d_keys[0], m->d_ids[0]);
+    size_t tb = m->sorttmp_bytes;
+    HIP_OK(hipcub::DeviceRadixSort::SortPairs(m->d_sorttmp, tb, m->d_keys[0], m->d_keys[1], m->d_ids[0], m->d_ids[1], (int)nrays, 0, 30, st));
+    a.order = m->d_ids[1];
+  }
   bool fixed = p->fixedstep != 0;
   if (m->kind == 1) {
     if (fixed) hipLaunchKernelGGL((trace_kernel<NgoModel, true, false>), dim3((unsigned)grid), dim3(WAVE), 0, st, (const NgoModel *)m->d_model, (const Common *)m->d_common, a);

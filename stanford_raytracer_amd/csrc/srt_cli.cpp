@@ -71,7 +71,7 @@ int main(int argc, char **argv) {
          "  model 3: --interp_interpfile --yearday --milliseconds_day --use_tsyganenko=0 --use_igrf=0\n"
          "  model 4: model 3 flags + --scattered_interp_window_scale --scattered_interp_order\n"
          "           --scattered_interp_exact --scattered_interp_local_window_scale\n"
-         "  extra:   --device=N  --first_attempt_policy=0|1  --chunk_rays=N\n"
+         "  extra:   --device=N  --first_attempt_policy=0|1  --chunk_rays=N  --ray_order=0|1\n"
          "  tools:   --grid2bin_in=<text grid> --grid2bin_out=<binary grid>   (convert and exit; --interp_interpfile\n"
          "           accepts either form)");
     return 0;
@@ -108,6 +108,7 @@ int main(int argc, char **argv) {
   get_int("outputper", p.outputper);
   get_int("device", device);
   get_int("first_attempt_policy", p.first_attempt_policy);
+  get_int("ray_order", p.ray_order);
   get_int("chunk_rays", chunk);
   int yearday = 0, msec = 0, use_tsy = 0, use_igrf = 0;
   need(get_int("yearday", yearday), "yearday");

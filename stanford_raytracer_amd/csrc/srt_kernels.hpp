@@ -19,6 +19,7 @@ struct TraceArgs {
   const double *pos0; // SoA [3][nrays]
   const double *dir0; // SoA [3][nrays]
   const double *w0;
+  const int *order;   // optional: queue position -> ray id (srt_params.ray_order); nullptr = identity
   long long nrays;
   double *rows;       // [nrays][slots][ROW]
   int *nrows;         // [nrays]
@@ -247,6 +248,7 @@ __global__ __launch_bounds__(64) void trace_kernel(const M *__restrict__ mp, con
         int rank = __popcll(freemask & ((1ull << lane) - 1ull));
         long long id = (long long)base + rank;
         if (id < a.nrays) {
+          if (a.order) id = a.order[id];
           ray = id;
           needinit = true;
           x[0] = a.pos0[id];

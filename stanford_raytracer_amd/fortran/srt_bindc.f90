@@ -12,7 +12,7 @@ module srt_bindc
 
   type, bind(C) :: srt_params
      real(c_double) :: dt0, dtmax, tmax, maxerr, minalt, del
-     integer(c_int32_t) :: maxsteps, root, fixedstep, outputper, first_attempt_policy, refill_threshold
+     integer(c_int32_t) :: maxsteps, root, fixedstep, outputper, first_attempt_policy, refill_threshold, ray_order
   end type srt_params
 
   interface

@@ -31,6 +31,7 @@ program srt_fortran_driver
   p%dt0 = 1.0e-3_c_double; p%dtmax = 0.1_c_double; p%tmax = 0.1_c_double; p%maxerr = 5.0e-4_c_double
   p%minalt = 6.4712e6_c_double; p%del = 1.0e-4_c_double
   p%maxsteps = 2000; p%root = 2; p%fixedstep = 1; p%outputper = 25; p%first_attempt_policy = 0; p%refill_threshold = 0
+  p%ray_order = 0
   slots = srt_rows_per_ray(p)
   allocate(rows(SRT_ROW*slots*nrays), nrows(nrays), stopcond(nrays))
   rc = srt_trace_batch(model, p, nrays, pos0, dir0, w0, rows, nrows, stopcond, steps)

@@ -152,3 +152,20 @@ def write_rays_file(path, pos0, dir0, w0):
     with open(path, "w") as f:
         for p, d, w in zip(pos0, dir0, w0):
             f.write(" ".join("%.17g" % v for v in (*p, *d, w)) + "\n")
+
+
+def morton_order(pos, half_width, n):
+    """Permutation that sorts launch points by the Morton code of their cell on an n^3 grid over +-half_width."""
+    c = np.clip(((np.asarray(pos) + half_width) / (2.0 * half_width) * (n - 1)).astype(np.int64), 0, n - 1)
+
+    def spread(v):
+        v = v & 0x1FFFFF
+        v = (v | (v << 32)) & 0x1F00000000FFFF
+        v = (v | (v << 16)) & 0x1F0000FF0000FF
+        v = (v | (v << 8)) & 0x100F00F00F00F00F
+        v = (v | (v << 4)) & 0x10C30C30C30C30C3
+        v = (v | (v << 2)) & 0x1249249249249249
+        return v
+
+    code = spread(c[:, 0]) | (spread(c[:, 1]) << 1) | (spread(c[:, 2]) << 2)
+    return np.argsort(code, kind="stable")

@@ -210,6 +210,19 @@ def check_invariants(pos, rows, nrows, stop, steps, p):
     return done
 
 
+def test_ray_order_option_changes_only_the_schedule(gpu_models):
+    """srt_params.ray_order = 1 works through the launch set sorted by launch cell; every ray's rows, row count and
+    stop code are bit-identical and stay at the ray's own index."""
+    m = gpu_models["interp"]
+    pos, d, w = wl.launch_set(5000, 31)
+    kw = dict(fixedstep=0, dt0=1e-3, dtmax=0.1, tmax=0.3, maxerr=5e-4, maxsteps=64, del_=1e-6, outputper=4)
+    a = m.trace(pos, d, w, **kw)
+    b = m.trace(pos, d, w, ray_order=1, **kw)
+    for x, y in zip(a[:3], b[:3]):
+        assert np.array_equal(x, y)
+    assert a[3] == b[3]
+
+
 def test_full_size_config2_ngo_100k(cfgfiles):
     """BASELINE config[1]: 100k rays, Ngo, adaptive RK45 -- size-independent properties."""
     from stanford_raytracer_amd import api
