@@ -171,6 +171,7 @@ def main():
     kernel_ms = []
     steps_acc = 0
     attempts = 0
+    wave_attempts = 0
     t_start = time.perf_counter()
     for _ in range(args.steps):
         one_step()
@@ -179,6 +180,7 @@ def main():
         c = d_cnt.cpu().numpy()
         steps_acc += int(c[1])
         attempts += int(c[2])
+        wave_attempts += int(c[3])
     sync_all()
     elapsed = time.perf_counter() - t_start
 
@@ -236,6 +238,7 @@ def main():
                          "accepted_steps_per_launch": steps_per_launch},
             "detail": {"attempts_per_launch": attempts / max(args.steps, 1),
                        "reject_ratio": 1.0 - steps_acc / max(attempts, 1),
+                       "lane_occupancy": attempts / max(64 * wave_attempts, 1),
                        "mean_rows_per_ray": float(nrows.mean()),
                        "stopcond_hist": {str(int(k)): int(v) for k, v in zip(*np.unique(stop, return_counts=True))},
                        "model_setup_s": setup_s, "model_device_GB": model.device_bytes / 1e9},

@@ -143,7 +143,7 @@ int srt_trace_batch(srt_model *m, const srt_params *p, int64_t nrays, const doub
 /* Same with every buffer already resident in device memory (what bench.py times).
  * d_pos0/d_dir0 are SoA on the device: [3][nrays].  stream = hipStream_t (NULL = default).
  * d_counters: 4 x int64 scratch/outputs: [0] queue head (zeroed by the call), [1] accepted steps,
- * [2] attempts, [3] reserved.  Asynchronous: returns after enqueue. */
+ * [2] attempts, [3] wave-attempts (lane occupancy = [2] / (64 * [3])).  Asynchronous: returns after enqueue. */
 int srt_trace_batch_device(srt_model *m, const srt_params *p, int64_t nrays, const double *d_pos0,
                            const double *d_dir0, const double *d_w0, double *d_rows,
                            int32_t *d_nrows, int32_t *d_stopcond, int64_t *d_counters, void *stream);

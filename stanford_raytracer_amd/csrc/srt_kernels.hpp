@@ -24,7 +24,7 @@ struct TraceArgs {
   double *rows;       // [nrays][slots][ROW]
   int *nrows;         // [nrays]
   int *stopcond;      // [nrays]
-  unsigned long long *counters; // [0] queue head, [1] accepted steps, [2] attempts
+  unsigned long long *counters; // [0] queue head, [1] accepted steps, [2] attempts, [3] wave-attempts (loop trips of all waves)
   TraceParams p;
 };
 
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(64) void trace_kernel(const M *__restrict__ mp, con
   double dirv[3] = {0, 0, 0};
   int nstep = 1, lastrefinedown = 0;
   bool first_attempt = true;
-  unsigned long long acc_steps = 0, acc_attempts = 0;
+  unsigned long long acc_steps = 0, acc_attempts = 0, wave_trips = 0;
   const int threshold = P.refill_threshold > 0 ? P.refill_threshold : 4;
 
   for (;;) {
@@ -328,6 +328,7 @@ __global__ __launch_bounds__(64) void trace_kernel(const M *__restrict__ mp, con
 
     // ---- E. one attempt for every lane (:770-817).  Stage 1 = r1 (carried); stages 2.. are evaluated here.
     acc_attempts += active ? 1ull : 0ull;
+    ++wave_trips;
     double est1[6], est2[6];
     {
       double ks[6][6];
@@ -481,6 +482,7 @@ __global__ __launch_bounds__(64) void trace_kernel(const M *__restrict__ mp, con
   if (lane == 0) {
     atomicAdd(a.counters + 1, acc_steps);
     atomicAdd(a.counters + 2, acc_attempts);
+    atomicAdd(a.counters + 3, wave_trips);
   }
 }
 
