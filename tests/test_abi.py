@@ -31,11 +31,22 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
 
 
-def test_struct_layout_matches_header():
+def test_struct_layout_matches_header(tmp_path):
+    """sizeof / offsetof of srt_params as the C compiler lays out include/srt.h == the ctypes mirror."""
+    import subprocess
+
     from stanford_raytracer_amd import api
 
-    # 6 doubles + 6 int32, no padding surprises
-    assert C.sizeof(api.Params) == 6 * 8 + 6 * 4
+    names = [f[0] for f in api.Params._fields_]
+    cnames = [("del" if n == "del_" else n) for n in names]
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "srt.h"\nint main(void){printf("%zu", sizeof(srt_params));'
+                   + "".join('printf(" %%zu", offsetof(srt_params, %s));' % n for n in cnames) + "return 0;}\n")
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)], check=True)
+    got = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert got[0] == C.sizeof(api.Params)
+    assert got[1:] == [getattr(api.Params, n).offset for n in names]
     p = api.make_params(maxsteps=256, outputper=16)
     assert api.lib().srt_rows_per_ray(C.byref(p)) == 16
     p = api.make_params(maxsteps=10, outputper=3)
