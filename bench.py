@@ -112,10 +112,14 @@ def main():
                             maxsteps=args.maxsteps or 64, outputper=8, del_=1e-6, refill_threshold=args.refill)
         t0 = time.time()
         npts = args.points or 825_000
-        pts, lnN = wl.make_points(int(npts * 0.97), npts - int(npts * 0.97), 5, half_width=10.0 * wl.R_E)
+        if npts == 825_000:  # 200 k uniform + 600 k importance-sampled + 25 k shell
+            pts, lnN = wl.make_points_config5(5)
+        else:
+            pts, lnN = wl.make_points(int(npts * 0.97), npts - int(npts * 0.97), 5, half_width=10.0 * wl.R_E)
         pfile = os.path.join(tempfile.mkdtemp(), "points.txt")
         wl.write_points_file(pfile, pts, lnN, np.array([-10.0 * wl.R_E, 10.0 * wl.R_E] * 3))
         model = api.Model.scattered_file(pfile, window_scale=1.5, order=2, exact=0, local_window_scale=5.0)
+        args.points_file = pfile
         setup_s = time.time() - t0
         wname = "%d rays/GPU, scattered_interp_dens_model (%d samples, order 2, window 1.5/5), dipole B, adaptive RK45" % (nrays, npts)
     else:
@@ -266,7 +270,7 @@ def cpu_baseline(args, kind, p, wl, pos0, dir0, w0, grid_n):
         om = oracle.Model.interp(F, bounds, wl.QS, wl.MS)
         del F
     elif kind == "scattered":
-        return {"skipped": "scattered CPU baseline not wired into bench (see BASELINE.md: reference 0.13 k steps/s/core)"}
+        om = oracle.Model.scattered_file(args.points_file, window_scale=1.5, order=2, exact=0, local_window_scale=5.0)
     else:
         cfg = os.path.join(tempfile.mkdtemp(), "newray.in")
         with open(cfg, "w") as f:

@@ -169,3 +169,35 @@ def morton_order(pos, half_width, n):
 
     code = spread(c[:, 0]) | (spread(c[:, 1]) << 1) | (spread(c[:, 2]) << 2)
     return np.argsort(code, kind="stable")
+
+
+def make_points_config5(seed, n_uniform=200_000, n_importance=600_000, n_shell=25_000, half_width=10.0 * R_E):
+    """The sample set of SURVEY.md 8(d) config 5 (825 k samples, the size of the manual's example): uniform in the
+    +-10 R_E cube, importance-sampled with density proportional to |grad ln N_e| of the same analytic plasmasphere
+    (rejection from the uniform proposal), and a shell between R_E and R_E + 2000 km.  Returns pts[n,3], lnN[n,4]."""
+    rng = np.random.default_rng(seed)
+    pu = rng.uniform(-half_width, half_width, (n_uniform, 3))
+
+    def gradmag(p):
+        h = 1.0e3
+        g = np.zeros(len(p))
+        for a in range(3):
+            e = np.zeros(3)
+            e[a] = h
+            g += ((analytic_lnN(p + e)[:, 0] - analytic_lnN(p - e)[:, 0]) / (2 * h)) ** 2
+        return np.sqrt(g)
+
+    probe = rng.uniform(-half_width, half_width, (200_000, 3))
+    cap = np.percentile(gradmag(probe), 99.5)  # acceptance = min(1, |grad| / cap)
+    chunks, have = [], 0
+    while have < n_importance:
+        c = rng.uniform(-half_width, half_width, (400_000, 3))
+        keep = c[rng.uniform(0.0, 1.0, len(c)) < np.minimum(gradmag(c) / cap, 1.0)]
+        chunks.append(keep)
+        have += len(keep)
+    pi = np.concatenate(chunks)[:n_importance]
+    v = rng.normal(size=(n_shell, 3))
+    v /= np.linalg.norm(v, axis=-1, keepdims=True)
+    ps = v * (R_E + rng.uniform(0.0, 2000e3, (n_shell, 1)))
+    pts = np.concatenate([pu, pi, ps], axis=0)
+    return pts, analytic_lnN(pts)
