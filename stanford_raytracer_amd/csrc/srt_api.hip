@@ -847,7 +847,7 @@ extern "C" int srt_trace_batch_device(srt_model *m, const srt_params *p, int64_t
   HIP_OK(hipMemsetAsync(d_counters, 0, 4 * sizeof(int64_t), st));
   // persistent grid: enough one-wave blocks to fill the chip, never more than the rays need
   long long want = (nrays + WAVE - 1) / WAVE;
-  int per_cu = (m->kind == 3) ? 4 : 8; // interp: 33 KB LDS tile per wave
+  int per_cu = (m->kind == 3 || m->kind == 4) ? 4 : 8; // interp / scattered: 34 KiB of LDS per wave, 512 registers per lane
   long long grid = (long long)m->cu_count * per_cu;
   if (grid > want) grid = want;
   if (grid < 1) grid = 1;

@@ -212,14 +212,14 @@ __global__ __launch_bounds__(64) void trace_kernel(const M *__restrict__ mp, con
   bool active = false, needinit = false;
   bool queue_empty = false; // wave-uniform
   double x[6] = {2.0 * R_E, 0.0, 0.5 * R_E, 1e-3, 0.0, 1e-4}; // benign state for lanes without a ray
-  double w = 2.0e4, t = 0.0, dt = P.dt0, w0 = w;
+  double w = 2.0e4, t = 0.0, dt = P.dt0;
   double vg[3] = {0, 0, 0};
   double r1[6] = {0, 0, 0, 0, 0, 0}; // evalrhs at the current state (first RK stage), carried across attempts
   double dirv[3] = {0, 0, 0};
   int nstep = 1, lastrefinedown = 0;
   bool first_attempt = true;
   unsigned long long acc_steps = 0, acc_attempts = 0, wave_trips = 0;
-  const int threshold = P.refill_threshold > 0 ? P.refill_threshold : 4;
+  const int threshold = P.refill_threshold > 0 ? P.refill_threshold : 1;
 
   for (;;) {
     // ---- A. loop-top tests of raytracer_run (:749-763)
@@ -257,71 +257,16 @@ __global__ __launch_bounds__(64) void trace_kernel(const M *__restrict__ mp, con
           dirv[0] = a.dir0[id];
           dirv[1] = a.dir0[a.nrays + id];
           dirv[2] = a.dir0[2 * a.nrays + id];
-          w0 = a.w0[id];
+          w = a.w0[id]; // (nothing reads a free lane's w before its launch evaluation)
         }
       }
       if ((long long)base + nfree >= a.nrays) queue_empty = true;
     }
-    // ---- C. initialise newly claimed rays (:661-742); whole wave takes the branch together.
-    // One staging serves the launch point AND the stencil of the first RK stage.
-    if (__any(needinit)) {
-      double p7[7][3], d7[3], N7[7][4];
-      stencil_points<7>(x, P.del, p7, d7);
-      m.template density_stencil<0>(x, d7, nullptr, N7, lds, needinit);
-      if (needinit) {
-        double B0[3];
-        bfield(cm.fld, x[0], x[1], x[2], B0);
-        double dir[3] = {dirv[0], dirv[1], dirv[2]};
-        if (dir[0] == 0.0 && dir[1] == 0.0 && dir[2] == 0.0) {
-          // field-aligned start: B/|B| with the radial component made positive (:661-674)
-          double rr = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
-          double er[3] = {x[0] / rr, x[1] / rr, x[2] / rr};
-          double br = B0[0] * er[0] + B0[1] * er[1] + B0[2] * er[2];
-          double adj = fabs(br) - br; // flip the radial part when negative
-#pragma unroll
-          for (int c = 0; c < 3; ++c) dir[c] = B0[c] + adj * er[c];
-          double nb = sqrt(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
-#pragma unroll
-          for (int c = 0; c < 3; ++c) dir[c] /= nb;
-        }
-        Roots rt = solve_dispersion(cm, dir, w0, N7[0], B0);
-        double kre = (P.root == 1) ? rt.k1re : rt.k2re;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) x[3 + c] = kre * dir[c]; // real(k0mag*dir0)
-        w = w0;
-        t = 0.0;
-        dt = P.dt0;
-        lastrefinedown = 0;
-        nstep = 1;
-        first_attempt = true;
-        // first-stage right-hand side + the group-velocity terms of row 0 (:700-742)
-        double dk[3], dw;
-        PointState ps;
-        rhs_from_plasma<7>(cm, x, x + 3, w, d7, p7, N7, r1, dk, dw, ps.B);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) ps.Ns[s] = N7[0][s];
-        double cw = cm.C / w;
-        double n[3] = {x[3] * cw, x[4] * cw, x[5] * cw};
-        double nn = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
-        double vp[3];
-        if (nn > 0.0) {
-#pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            vp[c] = n[c] / nn;
-            vg[c] = -(dk[c] / dw) / cm.C;
-          }
-        } else {
-#pragma unroll
-          for (int c = 0; c < 3; ++c) vp[c] = vg[c] = 0.0;
-        }
-        store_row(a.rows + (size_t)ray * (size_t)P.slots * ROW, t, x, vp, vg, n, ps);
-        active = true;
-        needinit = false;
-      }
-      continue; // new rays go through the loop-top tests before their first attempt
-    }
+    // ---- C. (newly claimed rays have no step of their own this trip: they ride along with the running ones and
+    // their launch point takes the place of the step's end point in E/F/G, see there; :661-742.  Every ray is
+    // initialised by that one code path, so its arithmetic does not depend on when it was claimed.)
     // ---- D. exit when nothing is left (every wave reaches this)
-    if (nfree == WAVE) {
+    if (!__any(active || needinit)) {
       if (queue_empty) break;
       continue;
     }
@@ -341,6 +286,10 @@ __global__ __launch_bounds__(64) void trace_kernel(const M *__restrict__ mp, con
         rk45_combine(x, ks, est1, est2);
       }
     }
+    if (needinit) { // a ray claimed this trip: its launch point is evaluated where the others evaluate their end point
+#pragma unroll
+      for (int c = 0; c < 3; ++c) est1[c] = est2[c] = x[c];
+    }
     bool reject = false;
     const double dtincr = dt;
     // One staging for everything evaluated at the step's end points: the plasma at est2 (error term, root
@@ -354,7 +303,7 @@ __global__ __launch_bounds__(64) void trace_kernel(const M *__restrict__ mp, con
       pp[NPOST - 1][1] = est1[1];
       pp[NPOST - 1][2] = est1[2];
     }
-    m.template density_stencil<NPOST - 7>(est2, dpost, FIXED ? nullptr : est1, NP_, lds, active);
+    m.template density_stencil<NPOST - 7>(est2, dpost, FIXED ? nullptr : est1, NP_, lds, active || needinit);
     PointState ps2;
 #pragma unroll
     for (int s = 0; s < 4; ++s) ps2.Ns[s] = NP_[0][s];
@@ -406,7 +355,25 @@ __global__ __launch_bounds__(64) void trace_kernel(const M *__restrict__ mp, con
       }
     }
     // ---- F. re-project |k| on the chosen root, keep direction (:819-836)
-    Roots rt = solve_dispersion(cm, est2 + 3, w, ps2.Ns, ps2.B);
+    double kdir[3] = {est2[3], est2[4], est2[5]};
+    if (needinit) { // launch direction (:661-674)
+      kdir[0] = dirv[0];
+      kdir[1] = dirv[1];
+      kdir[2] = dirv[2];
+      if (kdir[0] == 0.0 && kdir[1] == 0.0 && kdir[2] == 0.0) {
+        // field-aligned start: B/|B| with the radial component made positive
+        double rr = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+        double er[3] = {x[0] / rr, x[1] / rr, x[2] / rr};
+        double br = ps2.B[0] * er[0] + ps2.B[1] * er[1] + ps2.B[2] * er[2];
+        double adj = fabs(br) - br; // flip the radial part when negative
+#pragma unroll
+        for (int c = 0; c < 3; ++c) kdir[c] = ps2.B[c] + adj * er[c];
+        double nb = sqrt(kdir[0] * kdir[0] + kdir[1] * kdir[1] + kdir[2] * kdir[2]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) kdir[c] /= nb;
+      }
+    }
+    Roots rt = solve_dispersion(cm, kdir, w, ps2.Ns, ps2.B);
     double kmre = (P.root == 1) ? rt.k1re : rt.k2re;
     double kmim = (P.root == 1) ? rt.k1im : rt.k2im;
     double kn = sqrt(est2[3] * est2[3] + est2[4] * est2[4] + est2[5] * est2[5]);
@@ -414,14 +381,42 @@ __global__ __launch_bounds__(64) void trace_kernel(const M *__restrict__ mp, con
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       double u = est2[3 + c] / kn;
-      knew[c] = kmre * u;
+      knew[c] = needinit ? kmre * kdir[c] : kmre * u; // launch: real(k0mag*dir0) (:683-690)
       double im = kmim * u;
       imsum += im * im;
     }
     // first-stage right-hand side at the would-be new state (also yields its group-velocity terms)
     double rn[6], dk[3], dw, Bn[3];
     rhs_from_plasma<NPOST>(cm, est2, knew, w, dpost, pp, NP_, rn, dk, dw, Bn);
-    if (active && !reject) {
+    if (needinit) {
+      // launch state and row 0 (:693-742)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) x[3 + c] = knew[c];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) r1[c] = rn[c];
+      t = 0.0;
+      dt = P.dt0;
+      lastrefinedown = 0;
+      nstep = 1;
+      first_attempt = true;
+      double cw = cm.C / w;
+      double n[3] = {x[3] * cw, x[4] * cw, x[5] * cw};
+      double nn = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
+      double vp[3];
+      if (nn > 0.0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          vp[c] = n[c] / nn;
+          vg[c] = -(dk[c] / dw) / cm.C;
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) vp[c] = vg[c] = 0.0;
+      }
+      store_row(a.rows + (size_t)ray * (size_t)P.slots * ROW, t, x, vp, vg, n, ps2);
+      active = true;
+      needinit = false;
+    } else if (active && !reject) {
       first_attempt = false; // w = est2(7) is assigned from here on (:821)
       if (imsum > 0.0) {
         // outside the resonance cone (:891-906)

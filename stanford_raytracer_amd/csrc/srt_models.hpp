@@ -190,9 +190,10 @@ struct NgoModel {
 //     coef[cell][species][64]  doubles, cell = (ck*(ny+1)+cj)*(nx+1)+ci, ci = #nodes <= x (0..nx)
 // i.e. one contiguous 512 B block per (cell, species), 2 KiB per cell at nspec = 4 -- exactly the
 // 2048 B per lookup that the reference gathers from 8 arrays x 8 corners.  A lookup then is one
-// contiguous block read plus a polynomial evaluation.  Per wave the blocks of all 64 lanes are staged
-// species by species through a 33 KB LDS tile with fully coalesced 512 B reads, and every lane
-// evaluates all its stencil points from the tile.
+// contiguous block read plus a polynomial evaluation.  Per wave the blocks of all 64 lanes stream through a
+// ring of four 8-KiB LDS buffers, one k-plane (128 B per lane) of one species at a time, by LDS-DMA with a
+// lookahead of three units, and every lane evaluates all its stencil points from each unit (see
+// InterpModel::density_stencil).
 struct Axis {
   double min, del, rdel; // rdel = 1/del: only for the first guess of the cell search
   int n;
