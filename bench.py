@@ -196,6 +196,25 @@ def main():
         dist.all_reduce(s, op=dist.ReduceOp.SUM)
         tmax, tot_steps = float(t.item()), int(s.item())
 
+    stream_gbs = None
+    if rank == 0 and world == 1:
+        # the box's own streaming rate ("measure a device-to-device copy and use THAT as 100 %"): read +
+        # write bytes of a 2 GiB copy, outside the timed region
+        try:
+            src = torch.empty(1 << 28, dtype=torch.float64, device=dev)
+            dst = torch.empty_like(src)
+            dst.copy_(src)
+            torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                dst.copy_(src)
+            e1.record()
+            torch.cuda.synchronize(dev)
+            stream_gbs = 5 * 2 * src.numel() * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+            del src, dst
+        except Exception:
+            stream_gbs = None
     if rank == 0:
         stop = d_stop.cpu().numpy()
         nrows = d_nrows.cpu().numpy()
@@ -237,6 +256,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_GBs": (traffic / (k_ms * 1e-3) / 1e9) if traffic else None,
                          "traffic_frac": (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                         "stream_copy_GBs": stream_gbs,
                          "kernel": "trace_kernel<%s,adaptive>" % kind, "kernel_ms": k_ms,
                          "algorithmic_bytes_per_accepted_step": ALGO_BYTES_PER_STEP[kind](p.outputper),
                          "accepted_steps_per_launch": steps_per_launch},
