@@ -84,3 +84,45 @@ def test_binary_grid_is_the_same_model(tmp_path, grid16):
     ref = api.Model.interp(F, b, qs, ms).plasma_params(pos)
     for path in (txt, binf):
         assert np.array_equal(api.Model.interp_file(path).plasma_params(pos), ref)
+
+
+@pytest.mark.parametrize("modelnum", [3, 4])
+def test_cli_models_3_and_4_write_what_the_library_computes(tmp_path, grid16, pointsfile, modelnum):
+    """modelnum 3 / 4 through the CLI (adaptive RK45, outputper, chunked launches, --ray_order): the .ray file holds
+    exactly the rows the library returns for the same launch set, in the reference's record format."""
+    from stanford_raytracer_amd import api
+
+    pos, d, w = wl.launch_set(300, 17)
+    rf = tmp_path / "rays.txt"
+    wl.write_rays_file(str(rf), pos, d, w)
+    out = tmp_path / "out.ray"
+    common = ["--outputper=5", "--dt0=0.001", "--dtmax=0.1", "--tmax=0.05", "--root=2", "--fixedstep=0", "--maxerr=5e-4",
+              "--maxsteps=60", "--minalt=%r" % wl.MINALT, "--inputraysfile=%s" % rf, "--outputfile=%s" % out,
+              "--yearday=2010001", "--milliseconds_day=0", "--use_tsyganenko=0", "--use_igrf=0", "--chunk_rays=128",
+              "--ray_order=1", "--modelnum=%d" % modelnum]
+    if modelnum == 3:
+        F, b, qs, ms = grid16
+        gf = tmp_path / "grid.txt"
+        wl.write_grid_file(str(gf), F, b, qs, ms)
+        flags = ["--interp_interpfile=%s" % gf]
+        m = api.Model.interp(F, b, qs, ms)
+    else:
+        flags = ["--interp_interpfile=%s" % pointsfile, "--scattered_interp_window_scale=1.5", "--scattered_interp_order=2",
+                 "--scattered_interp_exact=0", "--scattered_interp_local_window_scale=5"]
+        m = api.Model.scattered_file(pointsfile)
+    subprocess.run([os.path.join(BIN, "raytracer")] + common + flags, check=True)
+    got = parse_ray_file(str(out))
+    rows, nrows, stop, _ = m.trace(pos, d, w, fixedstep=0, dt0=1e-3, dtmax=0.1, tmax=0.05, maxerr=5e-4, maxsteps=60,
+                                   minalt=wl.MINALT, del_=1e-6, outputper=5)
+    kept = (nrows + 4) // 5
+    assert len(got) == int(kept.sum())
+    at = 0
+    for r in range(len(w)):
+        blk = got[at:at + kept[r]]
+        at += kept[r]
+        assert np.all(blk[:, 0] == r + 1) and np.all(blk[:, 1] == stop[r])
+        want = rows[r, :kept[r]]
+        # es24.15e3 keeps 16 significant digits
+        assert np.allclose(blk[:, 2:18], want[:, 0:16], rtol=6e-16, atol=0)
+        assert np.allclose(blk[:, 28:32], want[:, 16:20], rtol=6e-16, atol=0)
+        assert np.allclose(blk[:, 18], w[r], rtol=6e-16)
