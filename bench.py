@@ -52,6 +52,7 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline sample duration (0=skip)")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--refill", type=int, default=0)
+    ap.add_argument("--streams", type=int, default=2, help="HIP streams the steps alternate on (1 = strictly serial)")
     ap.add_argument("--ray-order", type=int, default=1, choices=[0, 1],
                     help="srt_params.ray_order: 1 = the library works through the launch set sorted by launch cell "
                          "(device sort inside the timed region; SURVEY 8d allows this permutation), 0 = as given")
@@ -143,50 +144,61 @@ def main():
     d_pos = torch.from_numpy(np.ascontiguousarray(pos0.T)).to(dev)  # SoA [3][n]
     d_dir = torch.from_numpy(np.ascontiguousarray(dir0.T)).to(dev)
     d_w = torch.from_numpy(w0).to(dev)
-    d_rows = torch.zeros((nrays, slots, api.ROW), dtype=torch.float64, device=dev)
-    d_nrows = torch.zeros(nrays, dtype=torch.int32, device=dev)
-    d_stop = torch.zeros(nrays, dtype=torch.int32, device=dev)
-    d_cnt = torch.zeros(4, dtype=torch.int64, device=dev)
+    # Steps are issued alternately on `--streams` HIP streams (default 2), each with its own output buffers: the
+    # drain of one launch (queue empty, waves thinning out) overlaps the ramp-up of the next, and on N > 1 the RCCL
+    # gather of step k overlaps the kernel of step k+1.  All K steps complete inside the timed region.
+    nstream = max(1, args.streams)
+    streams = [torch.cuda.Stream(dev) for _ in range(nstream)] if nstream > 1 else [torch.cuda.current_stream(dev)]
+    outs = [{"rows": torch.zeros((nrays, slots, api.ROW), dtype=torch.float64, device=dev),
+             "nrows": torch.zeros(nrays, dtype=torch.int32, device=dev),
+             "stop": torch.zeros(nrays, dtype=torch.int32, device=dev)} for _ in range(nstream)]
+    d_rows, d_nrows, d_stop = outs[0]["rows"], outs[0]["nrows"], outs[0]["stop"]
     gather_buf = None
     if dist is not None and not args.no_gather and rank == 0:
         gather_buf = [torch.empty_like(d_rows) for _ in range(world)]
 
     import ctypes as C
 
-    stream = torch.cuda.current_stream(dev)
-
-    def one_step():
-        rc = api.lib().srt_trace_batch_device(model.h, C.byref(p), nrays, d_pos.data_ptr(), d_dir.data_ptr(),
-                                              d_w.data_ptr(), d_rows.data_ptr(), d_nrows.data_ptr(),
-                                              d_stop.data_ptr(), d_cnt.data_ptr(), stream.cuda_stream)
-        if rc != 0:
-            raise RuntimeError(api.lib().srt_last_error().decode())
-        if dist is not None and not args.no_gather:
-            dist.gather(d_rows, gather_buf, dst=0)
+    def one_step(i, cnt):
+        st, o = streams[i % nstream], outs[i % nstream]
+        with torch.cuda.stream(st):
+            rc = api.lib().srt_trace_batch_device(model.h, C.byref(p), nrays, d_pos.data_ptr(), d_dir.data_ptr(),
+                                                  d_w.data_ptr(), o["rows"].data_ptr(), o["nrows"].data_ptr(),
+                                                  o["stop"].data_ptr(), cnt.data_ptr(), st.cuda_stream)
+            if rc != 0:
+                raise RuntimeError(api.lib().srt_last_error().decode())
+            if dist is not None and not args.no_gather:
+                dist.gather(o["rows"], gather_buf, dst=0)
 
     def sync_all():
+        torch.cuda.synchronize(dev)
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        one_step()
+    torch.cuda.synchronize(dev)  # inputs are resident before anything is launched on the side streams
+    wcnt = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(args.warmup)]
+    for i in range(args.warmup):
+        one_step(i, wcnt[i])
     sync_all()
-    kernel_ms = []
-    steps_acc = 0
-    attempts = 0
-    wave_attempts = 0
+    cnts = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(args.steps)]
+    kernel_ms = [None] * args.steps
+    LAG = 2  # a launch's duration is read two launches later (the library keeps the events of the last 4 launches)
     t_start = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
-        # per-launch kernel duration from HIP events recorded on the launch stream inside the library
-        kernel_ms.append(model.last_kernel_ms())
-        c = d_cnt.cpu().numpy()
+    for i in range(args.steps):
+        one_step(i, cnts[i])
+        if i >= LAG:
+            kernel_ms[i - LAG] = model.launch_ms(LAG)
+    sync_all()
+    elapsed = time.perf_counter() - t_start
+    for i in range(max(0, args.steps - LAG), args.steps):
+        kernel_ms[i] = model.launch_ms(args.steps - 1 - i)
+    steps_acc = attempts = wave_attempts = 0
+    for c in cnts:
+        c = c.cpu().numpy()
         steps_acc += int(c[1])
         attempts += int(c[2])
         wave_attempts += int(c[3])
-    sync_all()
-    elapsed = time.perf_counter() - t_start
 
     tot_steps, tmax = steps_acc, elapsed
     if dist is not None:
@@ -247,7 +259,7 @@ def main():
             "config": {"workload": wname, "rays_per_gpu": nrays, "grid": grid_n, "maxsteps": p.maxsteps,
                        "outputper": p.outputper, "integrator": "rkf45 adaptive", "parallelism": "rays sharded x%d" % world,
                        "ray_order": "launch-cell Morton order, sorted on the device inside the timed region" if (args.ray_order and kind == "interp") else "as given",
-                       "gather": bool(dist is not None and not args.no_gather)},
+                       "gather": bool(dist is not None and not args.no_gather), "streams": nstream},
             # achieved/frac: ALGORITHMIC bytes (every lookup counted at 2 KiB) / kernel time -- exceeds the
             # HBM peak because consecutive lookups of a ray re-read the same block.  traffic: fabric-side bytes per
             # launch from the PMC passes (profiles/traffic_*.json); traffic_GBs = traffic / kernel time is the physical

@@ -150,6 +150,9 @@ int srt_trace_batch_device(srt_model *m, const srt_params *p, int64_t nrays, con
 /* duration in ms of the most recent trace kernel on this model, measured with HIP events on the
  * stream it ran on (synchronises that stream) */
 int srt_last_kernel_ms(srt_model *m, float *ms);
+/* the same for the launch `back` launches before the most recent one (0 .. 3): lets a caller that keeps several
+ * launches in flight on different streams read their durations afterwards */
+int srt_launch_ms(srt_model *m, int back, float *ms);
 
 /* ---- file formats of the boundary ---- */
 /* ray input file: 7 list-directed reals per line (raytracer_driver.f95:1146); returns count, fills

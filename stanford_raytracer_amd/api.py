@@ -82,6 +82,7 @@ def lib():
     L.srt_trace_batch.argtypes = [vp, C.POINTER(Params), C.c_int64, dp, dp, dp, dp, ip, ip, C.POINTER(C.c_int64)]
     L.srt_trace_batch_device.argtypes = [vp, C.POINTER(Params), C.c_int64, vp, vp, vp, vp, vp, vp, vp, vp]
     L.srt_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.srt_launch_ms.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
     L.srt_read_rays_file.argtypes = [C.c_char_p, C.POINTER(dp), C.POINTER(dp), C.POINTER(dp)]
     L.srt_read_rays_file.restype = C.c_int64
     L.srt_write_ray_file.argtypes = [C.c_char_p, C.c_int, C.c_int64, C.c_int64, C.POINTER(Params), C.c_int, dp, dp,
@@ -252,6 +253,11 @@ class Model:
         _check(lib().srt_trace_batch(self.h, C.byref(p), n, _dp(pos0), _dp(dir0), _dp(w0), _dp(rows),
                                      nrows.ctypes.data_as(ip), stop.ctypes.data_as(ip), C.byref(steps)))
         return rows, nrows, stop, steps.value
+
+    def launch_ms(self, back=0):
+        ms = C.c_float()
+        _check(lib().srt_launch_ms(self.h, back, C.byref(ms)))
+        return float(ms.value)
 
     def last_kernel_ms(self):
         ms = C.c_float()

@@ -79,14 +79,21 @@ struct srt_model {
   void *d_model = nullptr;   // device copy of ngo / interp (kernels read it through scalar loads)
   Common *d_common = nullptr;
   int64_t device_bytes = 0;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  bool timed = false;
   int cu_count = 256;
-  // scratch of the ray_order option (grow-only): keys in/out, ids in/out, radix-sort workspace
-  unsigned *d_keys[2] = {nullptr, nullptr};
-  int *d_ids[2] = {nullptr, nullptr};
-  void *d_sorttmp = nullptr;
-  size_t sort_cap = 0, sorttmp_bytes = 0;
+  // Per-launch scratch, in NSLOT rotating slots so that launches on different streams may overlap (a slot is
+  // reused only after the launch that used it has finished: `done` is waited on by the next user's stream).
+  struct LaunchSlot {
+    hipEvent_t ev0 = nullptr, ev1 = nullptr; // around the launch: srt_last_kernel_ms
+    bool used = false;
+    // ray_order option (grow-only): keys in/out, ids in/out, radix-sort workspace
+    unsigned *d_keys[2] = {nullptr, nullptr};
+    int *d_ids[2] = {nullptr, nullptr};
+    void *d_sorttmp = nullptr;
+    size_t sort_cap = 0, sorttmp_bytes = 0;
+  };
+  static constexpr int NSLOT = 4;
+  LaunchSlot slot[NSLOT];
+  int next_slot = 0, last_slot = -1;
 };
 
 static void fill_common(Common &cm, int nspec, const double *qs, const double *ms, int yearday, int msec) {
@@ -127,8 +134,10 @@ static int model_finish(srt_model *m) {
   hipDeviceProp_t p;
   HIP_OK(hipGetDeviceProperties(&p, g_device));
   m->cu_count = p.multiProcessorCount;
-  HIP_OK(hipEventCreate(&m->ev0));
-  HIP_OK(hipEventCreate(&m->ev1));
+  for (auto &sl : m->slot) {
+    HIP_OK(hipEventCreate(&sl.ev0));
+    HIP_OK(hipEventCreate(&sl.ev1));
+  }
   return SRT_OK;
 }
 
@@ -138,14 +147,16 @@ extern "C" void srt_model_destroy(srt_model *m) {
   if (m->d_pts) (void)hipFree(m->d_pts);
   if (m->d_cells) (void)hipFree(m->d_cells);
   if (m->d_model) (void)hipFree(m->d_model);
-  for (int k = 0; k < 2; ++k) {
-    if (m->d_keys[k]) (void)hipFree(m->d_keys[k]);
-    if (m->d_ids[k]) (void)hipFree(m->d_ids[k]);
+  for (auto &sl : m->slot) {
+    for (int k = 0; k < 2; ++k) {
+      if (sl.d_keys[k]) (void)hipFree(sl.d_keys[k]);
+      if (sl.d_ids[k]) (void)hipFree(sl.d_ids[k]);
+    }
+    if (sl.d_sorttmp) (void)hipFree(sl.d_sorttmp);
+    if (sl.ev0) (void)hipEventDestroy(sl.ev0);
+    if (sl.ev1) (void)hipEventDestroy(sl.ev1);
   }
-  if (m->d_sorttmp) (void)hipFree(m->d_sorttmp);
   if (m->d_common) (void)hipFree(m->d_common);
-  if (m->ev0) (void)hipEventDestroy(m->ev0);
-  if (m->ev1) (void)hipEventDestroy(m->ev1);
   delete m;
 }
 extern "C" int srt_model_kind(const srt_model *m) { return m ? m->kind : 0; }
@@ -851,38 +862,42 @@ extern "C" int srt_trace_batch_device(srt_model *m, const srt_params *p, int64_t
   long long grid = (long long)m->cu_count * per_cu;
   if (grid > want) grid = want;
   if (grid < 1) grid = 1;
-  HIP_OK(hipEventRecord(m->ev0, st));
+  srt_model::LaunchSlot &sl = m->slot[m->next_slot];
+  if (sl.used) HIP_OK(hipStreamWaitEvent(st, sl.ev1, 0)); // the slot's previous launch (maybe on another stream) is over
+  HIP_OK(hipEventRecord(sl.ev0, st));
   if (p->ray_order == 1 && m->kind == 3 && nrays > WAVE && nrays < (1ll << 31) && m->interp.ax.n < 1023 &&
       m->interp.ay.n < 1023 && m->interp.az.n < 1023) {
     // work through the launch set in the order of the rays' launch cells (inside the timed region)
-    if ((size_t)nrays > m->sort_cap) {
+    if ((size_t)nrays > sl.sort_cap) {
+      if (sl.used) HIP_OK(hipEventSynchronize(sl.ev1)); // about to free what that launch may still read
       for (int k = 0; k < 2; ++k) {
-        if (m->d_keys[k]) (void)hipFree(m->d_keys[k]);
-        if (m->d_ids[k]) (void)hipFree(m->d_ids[k]);
-        m->d_keys[k] = nullptr;
-        m->d_ids[k] = nullptr;
+        if (sl.d_keys[k]) (void)hipFree(sl.d_keys[k]);
+        if (sl.d_ids[k]) (void)hipFree(sl.d_ids[k]);
+        sl.d_keys[k] = nullptr;
+        sl.d_ids[k] = nullptr;
       }
-      m->sort_cap = 0;
+      sl.sort_cap = 0;
       for (int k = 0; k < 2; ++k) {
-        HIP_OK(hipMalloc(&m->d_keys[k], (size_t)nrays * sizeof(unsigned)));
-        HIP_OK(hipMalloc(&m->d_ids[k], (size_t)nrays * sizeof(int)));
+        HIP_OK(hipMalloc(&sl.d_keys[k], (size_t)nrays * sizeof(unsigned)));
+        HIP_OK(hipMalloc(&sl.d_ids[k], (size_t)nrays * sizeof(int)));
       }
-      m->sort_cap = (size_t)nrays;
+      sl.sort_cap = (size_t)nrays;
     }
     size_t need = 0;
-    HIP_OK(hipcub::DeviceRadixSort::SortPairs(nullptr, need, m->d_keys[0], m->d_keys[1], m->d_ids[0], m->d_ids[1], (int)nrays, 0, 30, st));
-    if (need > m->sorttmp_bytes) {
-      if (m->d_sorttmp) (void)hipFree(m->d_sorttmp);
-      m->d_sorttmp = nullptr;
-      m->sorttmp_bytes = 0;
-      HIP_OK(hipMalloc(&m->d_sorttmp, need));
-      m->sorttmp_bytes = need;
+    HIP_OK(hipcub::DeviceRadixSort::SortPairs(nullptr, need, sl.d_keys[0], sl.d_keys[1], sl.d_ids[0], sl.d_ids[1], (int)nrays, 0, 30, st));
+    if (need > sl.sorttmp_bytes) {
+      if (sl.used) HIP_OK(hipEventSynchronize(sl.ev1));
+      if (sl.d_sorttmp) (void)hipFree(sl.d_sorttmp);
+      sl.d_sorttmp = nullptr;
+      sl.sorttmp_bytes = 0;
+      HIP_OK(hipMalloc(&sl.d_sorttmp, need));
+      sl.sorttmp_bytes = need;
     }
     hipLaunchKernelGGL(ray_keys_kernel, dim3((unsigned)((nrays + 255) / 256)), dim3(256), 0, st, (const InterpModel *)m->d_model,
-                       d_pos0, (long long)nrays, m->d_keys[0], m->d_ids[0]);
-    size_t tb = m->sorttmp_bytes;
-    HIP_OK(hipcub::DeviceRadixSort::SortPairs(m->d_sorttmp, tb, m->d_keys[0], m->d_keys[1], m->d_ids[0], m->d_ids[1], (int)nrays, 0, 30, st));
-    a.order = m->d_ids[1];
+                       d_pos0, (long long)nrays, sl.d_keys[0], sl.d_ids[0]);
+    size_t tb = sl.sorttmp_bytes;
+    HIP_OK(hipcub::DeviceRadixSort::SortPairs(sl.d_sorttmp, tb, sl.d_keys[0], sl.d_keys[1], sl.d_ids[0], sl.d_ids[1], (int)nrays, 0, 30, st));
+    a.order = sl.d_ids[1];
   }
   bool fixed = p->fixedstep != 0;
   if (m->kind == 1) {
@@ -898,16 +913,29 @@ extern "C" int srt_trace_batch_device(srt_model *m, const srt_params *p, int64_t
     return srt_set_error(SRT_EINVAL, "model kind %d unsupported", m->kind);
   }
   HIP_OK(hipGetLastError());
-  HIP_OK(hipEventRecord(m->ev1, st));
-  m->timed = true;
+  HIP_OK(hipEventRecord(sl.ev1, st));
+  sl.used = true;
+  m->last_slot = m->next_slot;
+  m->next_slot = (m->next_slot + 1) % srt_model::NSLOT;
+  return SRT_OK;
+}
+
+extern "C" int srt_launch_ms(srt_model *m, int back, float *ms) {
+  if (!m || !ms) return srt_set_error(SRT_EINVAL, "null argument");
+  if (back < 0 || back >= srt_model::NSLOT || m->last_slot < 0) return srt_set_error(SRT_EINVAL, "no such launch");
+  srt_model::LaunchSlot &sl = m->slot[(m->last_slot - back + srt_model::NSLOT) % srt_model::NSLOT];
+  if (!sl.used) return srt_set_error(SRT_EINVAL, "no such launch");
+  HIP_OK(hipEventSynchronize(sl.ev1));
+  HIP_OK(hipEventElapsedTime(ms, sl.ev0, sl.ev1));
   return SRT_OK;
 }
 
 extern "C" int srt_last_kernel_ms(srt_model *m, float *ms) {
   if (!m || !ms) return srt_set_error(SRT_EINVAL, "null argument");
-  if (!m->timed) return srt_set_error(SRT_EINVAL, "no trace launched on this model yet");
-  HIP_OK(hipEventSynchronize(m->ev1));
-  HIP_OK(hipEventElapsedTime(ms, m->ev0, m->ev1));
+  if (m->last_slot < 0) return srt_set_error(SRT_EINVAL, "no trace launched on this model yet");
+  srt_model::LaunchSlot &sl = m->slot[m->last_slot];
+  HIP_OK(hipEventSynchronize(sl.ev1));
+  HIP_OK(hipEventElapsedTime(ms, sl.ev0, sl.ev1));
   return SRT_OK;
 }
 
