@@ -251,6 +251,43 @@ bool write_grid_binary(const char *path, const GridFile &g, std::string &err) {
   return ok;
 }
 
+// every numeric token of a text file, in order, parsed by all host cores; false if the file cannot be opened or holds
+// a non-numeric token
+bool read_all_numbers(const char *path, std::vector<double> &all, std::string &err) {
+  MappedFile mf(path);
+  if (!mf.p) { err = "cannot open"; return false; }
+  const char *b = mf.p, *e = mf.p + mf.n;
+  unsigned nt = std::thread::hardware_concurrency();
+  nt = nt ? (nt > 32 ? 32 : nt) : 1;
+  if ((size_t)(e - b) < (size_t)nt * 4096) nt = 1;
+  std::vector<const char *> cut(nt + 1);
+  cut[0] = b;
+  cut[nt] = e;
+  for (unsigned t = 1; t < nt; ++t) {
+    const char *c = b + (size_t)(e - b) * t / nt;
+    const char *nl = (const char *)memchr(c, '\n', (size_t)(e - c));
+    cut[t] = nl ? nl + 1 : e;
+  }
+  std::vector<std::vector<double>> part(nt);
+  std::vector<char> good(nt, 1);
+  std::vector<std::thread> th;
+  for (unsigned t = 0; t < nt; ++t)
+    th.emplace_back([&, t] {
+      part[t].reserve((size_t)(cut[t + 1] - cut[t]) / 16 + 16);
+      good[t] = parse_tokens(cut[t], cut[t + 1], part[t]) ? 1 : 0;
+    });
+  for (auto &x : th) x.join();
+  size_t total = 0;
+  for (unsigned t = 0; t < nt; ++t) {
+    if (!good[t]) { err = "non-numeric token"; return false; }
+    total += part[t].size();
+  }
+  all.clear();
+  all.reserve(total);
+  for (unsigned t = 0; t < nt; ++t) all.insert(all.end(), part[t].begin(), part[t].end());
+  return true;
+}
+
 bool read_grid_file(const char *path, GridFile &g, std::string &err) {
   if (is_binary_grid(path)) return read_grid_binary(path, g, err);
   MappedFile mf(path);

@@ -49,6 +49,9 @@ private:
   std::vector<char> line_;
 };
 
+// every numeric token of a text file in order, parsed by all host cores
+bool read_all_numbers(const char *path, std::vector<double> &all, std::string &err);
+
 // es24.15e3 edit descriptor
 void format_es24(double v, char out[25]);
 

@@ -3,7 +3,8 @@
 // Launch shape: blocks of exactly one wave (64 threads); one ray per lane.  The trace kernel is
 // persistent: each wave pulls rays from a global queue, integrates all its lanes in lock step (one
 // RK attempt per loop trip) and refills lanes whose rays have stopped (wavefront ballot + one atomic
-// per refill) until the queue is empty -- every wave reaches that exit.
+// per refill; a new ray's launch point is evaluated in the running rays' end-point slot of that trip)
+// until the queue is empty -- every wave reaches that exit.
 #pragma once
 #include "srt_models.hpp"
 
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(64) void trace_kernel(const M *__restrict__ mp, con
           dirv[0] = a.dir0[id];
           dirv[1] = a.dir0[a.nrays + id];
           dirv[2] = a.dir0[2 * a.nrays + id];
-          w = a.w0[id]; // (nothing reads a free lane's w before its launch evaluation)
+          w = a.w0[id];
         }
       }
       if ((long long)base + nfree >= a.nrays) queue_empty = true;

@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstring>
 #include <numeric>
+#include <thread>
 
 #include "srt_host.hpp"
 
@@ -46,20 +47,43 @@ void build_grid(const std::vector<double> &xyz, int n, double cell, const double
 } // namespace
 
 bool build_scattered(const char *path, double window_scale, ScatteredHost &out, std::string &err) {
-  ListReader r(path);
-  if (!r.ok()) {
-    err = "cannot open";
-    return false;
-  }
-  double hdr[7];
-  if (r.read(7, hdr) != 7) { err = "header (nspec + bounds) incomplete"; return false; }
-  int nspec = (int)hdr[0];
-  if (nspec < 1 || nspec > 4) { err = "nspec must be 1..4"; return false; }
-  out.nspec = nspec;
-  if (r.read(nspec, out.qs) != nspec || r.read(nspec, out.ms) != nspec) { err = "charges/masses incomplete"; return false; }
   std::vector<double> raw;
-  double row[8];
-  while (r.read(3 + nspec, row) == 3 + nspec) raw.insert(raw.end(), row, row + 3 + nspec);
+  int nspec = 0;
+  {
+    // fast path: the whole file tokenised by all cores; valid when every record holds exactly what its READ takes
+    // (7 header numbers, nspec charges, nspec masses, then 3 + nspec numbers per sample)
+    std::vector<double> all;
+    std::string e2;
+    bool fast = read_all_numbers(path, all, e2) && all.size() >= 7;
+    if (fast) {
+      nspec = (int)all[0];
+      fast = nspec >= 1 && nspec <= 4 && all.size() >= (size_t)(7 + 2 * nspec) &&
+             (all.size() - 7 - 2 * nspec) % (size_t)(3 + nspec) == 0;
+    }
+    if (fast) {
+      out.nspec = nspec;
+      for (int k = 0; k < nspec; ++k) {
+        out.qs[k] = all[7 + k];
+        out.ms[k] = all[7 + nspec + k];
+      }
+      raw.assign(all.begin() + 7 + 2 * nspec, all.end());
+    } else {
+      // the Fortran's record semantics, one READ at a time
+      ListReader r(path);
+      if (!r.ok()) {
+        err = "cannot open";
+        return false;
+      }
+      double hdr[7];
+      if (r.read(7, hdr) != 7) { err = "header (nspec + bounds) incomplete"; return false; }
+      nspec = (int)hdr[0];
+      if (nspec < 1 || nspec > 4) { err = "nspec must be 1..4"; return false; }
+      out.nspec = nspec;
+      if (r.read(nspec, out.qs) != nspec || r.read(nspec, out.ms) != nspec) { err = "charges/masses incomplete"; return false; }
+      double row[8];
+      while (r.read(3 + nspec, row) == 3 + nspec) raw.insert(raw.end(), row, row + 3 + nspec);
+    }
+  }
   const int w = 3 + nspec;
   int n0 = (int)(raw.size() / w);
   if (n0 == 0) { err = "no samples"; return false; }
@@ -99,8 +123,13 @@ bool build_scattered(const char *path, double window_scale, ScatteredHost &out, 
   Grid g;
   build_grid(xyz, n, cell, lo, hi, g);
   std::vector<double> nn(n, 1.0); // placeholder 1.0 for samples inside the Earth (scattered_..adapter.f95:152)
+  unsigned nthr = std::thread::hardware_concurrency();
+  nthr = nthr ? (nthr > 32 ? 32 : nthr) : 1;
+  if (n < 20000) nthr = 1;
+  std::vector<double> maxn(nthr, 0.0);
+  auto nn_range = [&](unsigned tid, int i0, int i1) {
   double maxnearest = 0.0;
-  for (int i = 0; i < n; ++i) {
+  for (int i = i0; i < i1; ++i) {
     const double *p = &xyz[3 * (size_t)i];
     if (p[0] * p[0] + p[1] * p[1] + p[2] * p[2] < R_E * R_E) continue;
     int c[3] = {g.cell_of(p, 0), g.cell_of(p, 1), g.cell_of(p, 2)};
@@ -129,6 +158,16 @@ bool build_scattered(const char *path, double window_scale, ScatteredHost &out, 
       maxnearest = std::max(maxnearest, nn[i]);
     }
   }
+  maxn[tid] = maxnearest;
+  };
+  {
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nthr; ++t)
+      th.emplace_back(nn_range, t, (int)((long long)n * t / nthr), (int)((long long)n * (t + 1) / nthr));
+    for (auto &x : th) x.join();
+  }
+  double maxnearest = 0.0;
+  for (double v : maxn) maxnearest = std::max(maxnearest, v);
   out.maxnearest = maxnearest;
   out.radius = maxnearest * window_scale;
   if (!(out.radius > 0)) { err = "degenerate sample set (max nearest distance is zero)"; return false; }
