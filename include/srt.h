@@ -104,6 +104,29 @@ int srt_build_grid(srt_model *src, int compder, int nx, int ny, int nz, const do
                    double *derivs);
 int srt_model_create_interp_from_model(srt_model *src, int compder, int nx, int ny, int nz,
                                        const double bounds[6], int yearday, int msec, srt_model **out);
+/* The other builder of the step before the path: the random / adaptive sample set of
+ * gcpm_dens_model_buildgrid_random.f95:228-407 + randomsampling_mod.f95:27-200 (recursivesampler), with any model
+ * handle in place of GCPM, generated and refined ON THE DEVICE.  Stage order and per-stage rules are the reference's:
+ * points of an existing file first (in_pts, kept and pushed to the output), n_initial_radial shell samples retried
+ * until inside the box, n_initial_uniform samples, adaptive passes with tol = initial_tol, tol/2, ... until
+ * adaptive_nmax adaptive samples exist, n_zero_altitude samples on the sphere r = R_E and n_iri_pad samples in the
+ * shell R_E .. R_E+2000 km (both kept only when inside the box).  The recursion of one pass is evaluated level by
+ * level (all half-boxes of one depth at once) from counter-based random numbers, so the set is a pure function of
+ * `seed` (the reference seeds from the clock).  max_passes bounds the tolerance-halving loop, which the reference
+ * leaves unbounded (0 = 64).  out = malloc'd [n_out][3+nspec] records "x y z lnN_1..lnN_nspec", the lines of the
+ * model-4 file (srt_free); stage_counts[6] = samples from {input, radial, uniform, adaptive, zero altitude, iri}. */
+typedef struct srt_sampler_params {
+  double bounds[6];          /* minx maxx miny maxy minz maxz */
+  int64_t n_zero_altitude, n_iri_pad, n_initial_radial, n_initial_uniform, adaptive_nmax;
+  double initial_tol;
+  int32_t max_recursion;
+  int32_t numincrease;       /* the reference passes 5 (gcpm_dens_model_buildgrid_random.f95:338); 0 = 5 */
+  int32_t max_passes;
+  int32_t reserved;
+  uint64_t seed;
+} srt_sampler_params;
+int srt_build_samples(srt_model *src, const srt_sampler_params *sp, int64_t n_in, const double *in_pts,
+                      int64_t *n_out, double **out, int64_t stage_counts[6]);
 void srt_model_destroy(srt_model *m);
 int srt_model_kind(const srt_model *m);  /* 1, 3 or 4 */
 int srt_model_nspec(const srt_model *m);

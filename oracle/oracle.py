@@ -11,7 +11,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "libsrt_oracle.so")
-SRCS = ["srt_oracle.c", "srt_oracle_scattered.c"]
+SRCS = ["srt_oracle.c", "srt_oracle_scattered.c", "srt_oracle_sampler.c"]
 ROW = 20
 
 
@@ -69,6 +69,11 @@ def lib():
         L.so_trace_batch.restype = C.c_long
         L.so_trace_batch.argtypes = [C.c_void_p, C.POINTER(Params), C.c_long, dp, dp, dp, dp, C.c_int, ip, ip,
                                      C.c_int]
+        lp = C.POINTER(C.c_long)
+        L.so_build_samples.restype = C.c_void_p
+        L.so_build_samples.argtypes = [C.c_void_p, dp, lp, C.c_double, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_long, dp,
+                                       lp, lp]
+        L.so_free.argtypes = [C.c_void_p]
         L.so_dipole_tilt.argtypes = [C.c_int, C.c_int, dp]
         L.so_speed_of_light.restype = C.c_double
         _lib = L
@@ -126,6 +131,28 @@ class Model:
             pass
 
     # ---- layers
+    def build_samples(self, bounds, n_zero_altitude=0, n_iri_pad=0, n_initial_radial=0, n_initial_uniform=0,
+                      adaptive_nmax=0, initial_tol=1.0, max_recursion=20, numincrease=5, max_passes=0, seed=0,
+                      input_points=None):
+        """Depth-first restatement of the reference's sample-set builder (srt_oracle_sampler.c)."""
+        L = lib()
+        w = 3 + self.nspec
+        counts = (C.c_long * 5)(n_zero_altitude, n_iri_pad, n_initial_radial, n_initial_uniform, adaptive_nmax)
+        n_in, inp = 0, None
+        if input_points is not None:
+            inp = _arr(input_points).reshape(-1, w)
+            n_in = inp.shape[0]
+        n_out = C.c_long()
+        sc = (C.c_long * 6)()
+        p = L.so_build_samples(self.h, _dp(_arr(bounds, 6)), counts, initial_tol, max_recursion, numincrease, max_passes,
+                               seed, n_in, _dp(inp) if n_in else None, C.byref(n_out), sc)
+        try:
+            a = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_double)), shape=(n_out.value, w)).copy() if n_out.value \
+                else np.empty((0, w))
+        finally:
+            L.so_free(p)
+        return a, list(sc)
+
     def plasma_params(self, x):
         x = _arr(x, 3)
         qs, Ns, ms, nus, B0 = (np.zeros(4), np.zeros(4), np.zeros(4), np.zeros(4), np.zeros(3))

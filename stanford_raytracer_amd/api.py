@@ -40,6 +40,14 @@ dp = C.POINTER(C.c_double)
 ip = C.POINTER(C.c_int32)
 
 
+class SamplerParams(C.Structure):
+    """srt_sampler_params of include/srt.h (the flags of gcpm_dens_model_buildgrid_random.f95:56-90)."""
+    _fields_ = [("bounds", C.c_double * 6), ("n_zero_altitude", C.c_int64), ("n_iri_pad", C.c_int64),
+                ("n_initial_radial", C.c_int64), ("n_initial_uniform", C.c_int64), ("adaptive_nmax", C.c_int64),
+                ("initial_tol", C.c_double), ("max_recursion", C.c_int32), ("numincrease", C.c_int32),
+                ("max_passes", C.c_int32), ("reserved", C.c_int32), ("seed", C.c_uint64)]
+
+
 def library_path():
     return _build.LIB
 
@@ -92,6 +100,8 @@ def lib():
     L.srt_build_grid.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, dp, dp, dp]
     L.srt_model_create_interp_from_model.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, dp, C.c_int, C.c_int,
                                                      C.POINTER(vp)]
+    L.srt_build_samples.argtypes = [vp, C.POINTER(SamplerParams), C.c_int64, dp, C.POINTER(C.c_int64), C.POINTER(dp),
+                                    C.POINTER(C.c_int64)]
     i32p = C.POINTER(C.c_int32)
     L.srt_grid_file_read.argtypes = [C.c_char_p, i32p, dp, dp, dp, C.POINTER(dp), C.POINTER(dp)]
     L.srt_grid_file_write.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, dp, dp, dp, dp, dp]
@@ -182,6 +192,33 @@ class Model:
         _check(lib().srt_build_grid(self.h, int(bool(compder)), nx, ny, nz, _dp(_f64(bounds, (6,))), _dp(F),
                                     _dp(D) if compder else None))
         return F, (list(D) if compder else None)
+
+    def build_samples(self, bounds, n_zero_altitude=0, n_iri_pad=0, n_initial_radial=0, n_initial_uniform=0,
+                      adaptive_nmax=0, initial_tol=1.0, max_recursion=20, numincrease=5, max_passes=0, seed=0,
+                      input_points=None):
+        """The reference's random / adaptive sample-set builder with this model in place of GCPM, on the device.
+        -> (samples[n, 3+nspec] = the lines "x y z lnN_1.." of a model-4 file, stage_counts[6])."""
+        sp = SamplerParams()
+        sp.bounds[:] = [float(b) for b in bounds]
+        sp.n_zero_altitude, sp.n_iri_pad = int(n_zero_altitude), int(n_iri_pad)
+        sp.n_initial_radial, sp.n_initial_uniform = int(n_initial_radial), int(n_initial_uniform)
+        sp.adaptive_nmax, sp.initial_tol, sp.max_recursion = int(adaptive_nmax), float(initial_tol), int(max_recursion)
+        sp.numincrease, sp.max_passes, sp.seed = int(numincrease), int(max_passes), int(seed)
+        w = 3 + self.nspec
+        n_in, inp = 0, None
+        if input_points is not None:
+            inp = _f64(input_points).reshape(-1, w)
+            n_in = inp.shape[0]
+        n_out = C.c_int64()
+        out = dp()
+        counts = (C.c_int64 * 6)()
+        _check(lib().srt_build_samples(self.h, C.byref(sp), n_in, _dp(inp) if n_in else None, C.byref(n_out),
+                                       C.byref(out), counts))
+        try:
+            res = np.ctypeslib.as_array(out, shape=(n_out.value, w)).copy() if n_out.value else np.empty((0, w))
+        finally:
+            lib().srt_free(out)
+        return res, list(counts)
 
     def to_interp(self, nx, ny, nz, bounds, compder=False, yearday=2010001, msec=0):
         """A modelnum=3 model tabulating this one, built without leaving the device."""

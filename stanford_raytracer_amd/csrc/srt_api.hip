@@ -15,6 +15,7 @@
 #include "srt_host.hpp"
 #include "srt_kernels.hpp"
 #include "srt_scattered.hpp"
+#include "srt_sampler.hpp"
 #include <hipcub/hipcub.hpp>
 #include "tricubic_matrix.h"
 
@@ -790,6 +791,229 @@ extern "C" int srt_rk_step(srt_model *m, int64_t n, const double *args, const do
   else return srt_set_error(SRT_EINVAL, "model kind %d unsupported", m->kind);
   HIP_OK(hipMemcpy(out, dout.p, 21 * n * sizeof(double), hipMemcpyDeviceToHost));
   return SRT_OK;
+}
+
+
+// ---- the random / adaptive sample-set builder (kernels and the level-by-level scheme: srt_sampler.hpp) ----
+namespace {
+struct DevMem { // grow-only device buffer
+  void *p = nullptr;
+  size_t cap = 0;
+  ~DevMem() {
+    if (p) (void)hipFree(p);
+  }
+  // at least `bytes`; the first `keep` bytes survive a reallocation
+  int reserve(size_t bytes, size_t keep = 0) {
+    if (bytes <= cap) return 0;
+    size_t want = bytes + bytes / 2 + 4096;
+    void *q = nullptr;
+    if (hipMalloc(&q, want) != hipSuccess) return -1;
+    if (p && keep && hipMemcpy(q, p, keep, hipMemcpyDeviceToDevice) != hipSuccess) {
+      (void)hipFree(q);
+      return -1;
+    }
+    if (p) (void)hipFree(p);
+    p = q;
+    cap = want;
+    return 0;
+  }
+  template <class T> T *as() { return (T *)p; }
+};
+} // namespace
+
+static void smp_eval(srt_model *src, long long n, double *rec) {
+  if (n <= 0) return;
+  if (src->kind == 1) launch_wave_blocks(smp_eval_kernel<NgoModel, false>, n, 0, (const NgoModel *)src->d_model, n, rec);
+  else if (src->kind == 3) launch_wave_blocks(smp_eval_kernel<InterpModel, true>, n, 0, (const InterpModel *)src->d_model, n, rec);
+  else launch_wave_blocks(smp_eval_kernel<ScatteredModel, false>, n, 0, (const ScatteredModel *)src->d_model, n, rec);
+}
+
+extern "C" int srt_build_samples(srt_model *src, const srt_sampler_params *sp, int64_t n_in, const double *in_pts,
+                                 int64_t *n_out, double **out, int64_t stage_counts[6]) {
+  if (!src || !sp || !n_out || !out || n_in < 0 || (n_in > 0 && !in_pts)) return srt_set_error(SRT_EINVAL, "bad argument");
+  if (src->kind != 1 && src->kind != 3 && src->kind != 4) return srt_set_error(SRT_EINVAL, "model kind %d unsupported", src->kind);
+  const double *bd = sp->bounds;
+  if (!(bd[1] > bd[0]) || !(bd[3] > bd[2]) || !(bd[5] > bd[4])) return srt_set_error(SRT_EINVAL, "empty bounds");
+  if (sp->n_zero_altitude < 0 || sp->n_iri_pad < 0 || sp->n_initial_radial < 0 || sp->n_initial_uniform < 0 || sp->max_recursion < 0 ||
+      sp->numincrease < 0)
+    return srt_set_error(SRT_EINVAL, "negative count");
+  int rc = ensure_init();
+  if (rc) return rc;
+  const int nspec = src->nspec, ninc = sp->numincrease ? sp->numincrease : 5;
+  if (ninc > WAVE) return srt_set_error(SRT_EINVAL, "numincrease > %d", WAVE);
+  const int max_passes = sp->max_passes > 0 ? sp->max_passes : 64;
+  SmpBox root;
+  for (int c = 0; c < 3; ++c) {
+    root.lo[c] = bd[2 * c];
+    root.hi[c] = bd[2 * c + 1];
+  }
+  root.id = 1;
+  int64_t counts[6] = {n_in, 0, 0, 0, 0, 0};
+  const size_t RB = SMP_REC * sizeof(double);
+  DevMem pool, slot, stage, valid;
+  long long npool = 0;
+#define SMP_OK(expr)                                                                        \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess) return srt_set_error(SRT_EDEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+#define SMP_MEM(expr)                                                           \
+  do {                                                                          \
+    if ((expr)) return srt_set_error(SRT_ENOMEM, "device allocation failed (sampler)"); \
+  } while (0)
+
+  // (0) points of an existing file: part of the initial set and of the output (:210-227)
+  if (n_in > 0) {
+    std::vector<double> h((size_t)n_in * SMP_REC, 0.0);
+    for (int64_t i = 0; i < n_in; ++i)
+      for (int c = 0; c < 3 + nspec; ++c) h[(size_t)i * SMP_REC + c] = in_pts[(size_t)i * (3 + nspec) + c];
+    SMP_MEM(pool.reserve(h.size() * sizeof(double)));
+    SMP_OK(hipMemcpy(pool.p, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
+    npool = n_in;
+  }
+  // shell and uniform stages share one routine: positions, f(x), then append (device) or compact (host)
+  std::vector<double> tail; // zero-altitude and ionosphere samples, appended to the output after the pool
+  auto run_stage = [&](int stg, long long n, double rmin, double rmax, bool to_pool, int64_t &count) -> int {
+    if (n <= 0) return SRT_OK;
+    SMP_MEM(stage.reserve((size_t)n * RB));
+    SMP_MEM(valid.reserve((size_t)n * sizeof(int)));
+    hipLaunchKernelGGL(smp_stage_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, stg, n, (unsigned long long)sp->seed, root, rmin,
+                       rmax, stage.as<double>(), valid.as<int>());
+    smp_eval(src, n, stage.as<double>());
+    SMP_OK(hipDeviceSynchronize());
+    if (to_pool) {
+      std::vector<int> hv((size_t)n);
+      SMP_OK(hipMemcpy(hv.data(), valid.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+      for (long long i = 0; i < n; ++i)
+        if (!hv[i])
+          return srt_set_error(SRT_EINVAL, "radial stage: sample %lld found no point of the shell inside the box in %d attempts", i, SMP_MAXTRY);
+      SMP_MEM(pool.reserve((size_t)(npool + n) * RB, (size_t)npool * RB));
+      SMP_OK(hipMemcpy(pool.as<double>() + (size_t)npool * SMP_REC, stage.p, (size_t)n * RB, hipMemcpyDeviceToDevice));
+      npool += n;
+      count = n;
+    } else {
+      std::vector<int> hv((size_t)n);
+      std::vector<double> hr((size_t)n * SMP_REC);
+      SMP_OK(hipMemcpy(hv.data(), valid.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+      SMP_OK(hipMemcpy(hr.data(), stage.p, (size_t)n * RB, hipMemcpyDeviceToHost));
+      for (long long i = 0; i < n; ++i)
+        if (hv[i]) {
+          for (int c = 0; c < 3 + nspec; ++c) tail.push_back(hr[(size_t)i * SMP_REC + c]);
+          ++count;
+        }
+    }
+    return SRT_OK;
+  };
+  // (1) radial (:228-272): rmin = R_E, rmax = the farthest corner of the box
+  {
+    double r2 = 0.0;
+    for (int q = 0; q < 8; ++q) {
+      const double x = bd[q & 4 ? 1 : 0], y = bd[q & 2 ? 3 : 2], z = bd[q & 1 ? 5 : 4];
+      const double v = x * x + y * y + z * z;
+      if (v > r2) r2 = v;
+    }
+    if ((rc = run_stage(SMP_RADIAL, sp->n_initial_radial, R_E, sqrt(r2), true, counts[1]))) return rc;
+  }
+  // (2) uniform (:275-296)
+  if ((rc = run_stage(SMP_UNIFORM, sp->n_initial_uniform, 0.0, 0.0, true, counts[2]))) return rc;
+
+  // (3) adaptive (:298-347): tol halves until adaptive_nmax adaptive samples exist
+  if (sp->adaptive_nmax > 0) {
+    DevMem keys0, keys1, idx0, idx1, sorttmp, callsA, callsB, halves, cand, nadd, refine, addA, addoff, childoff, scantmp;
+    DevMem *calls = &callsA, *children = &callsB;
+    int64_t nsamples = 0;
+    double tol = sp->initial_tol;
+    for (int pass = 0; nsamples < sp->adaptive_nmax && pass < max_passes; ++pass, tol = tol / 2.0) {
+      if (npool >= (1ll << 31) - (1ll << 26)) return srt_set_error(SRT_EINVAL, "sample pool too large");
+      SMP_MEM(slot.reserve((size_t)npool * sizeof(int)));
+      if (npool > 0) hipLaunchKernelGGL(smp_fill_int, dim3((unsigned)((npool + 255) / 256)), dim3(256), 0, 0, npool, slot.as<int>(), 0);
+      SMP_MEM(calls->reserve(sizeof(SmpBox)));
+      SMP_OK(hipMemcpy(calls->p, &root, sizeof(SmpBox), hipMemcpyHostToDevice));
+      long long ncalls = 1;
+      for (int depth = 0; depth <= sp->max_recursion && ncalls > 0; ++depth) {
+        const int dim = depth % 3;
+        const long long nhalf = 2 * ncalls;
+        if (nhalf > (1ll << 26)) return srt_set_error(SRT_EINVAL, "adaptive sampler: %lld half-boxes at depth %d (tolerance too small)", nhalf, depth);
+        const long long ncand = nhalf * 2 * ninc;
+        SMP_MEM(keys0.reserve((size_t)npool * 4 + 4) || keys1.reserve((size_t)npool * 4 + 4) || idx0.reserve((size_t)npool * 4 + 4) ||
+                idx1.reserve((size_t)npool * 4 + 4));
+        SMP_MEM(halves.reserve((size_t)nhalf * sizeof(SmpBox)) || cand.reserve((size_t)ncand * RB));
+        SMP_MEM(nadd.reserve((size_t)nhalf * 4) || refine.reserve((size_t)nhalf * 4) || addA.reserve((size_t)nhalf * 4) ||
+                addoff.reserve((size_t)nhalf * 4) || childoff.reserve((size_t)nhalf * 4));
+        if (npool > 0) {
+          hipLaunchKernelGGL(smp_keys_kernel, dim3((unsigned)((npool + 255) / 256)), dim3(256), 0, 0, npool, pool.as<double>(), slot.as<int>(),
+                             calls->as<SmpBox>(), dim, (unsigned)nhalf, keys0.as<unsigned>(), idx0.as<int>());
+          int bits = 1;
+          while ((1ll << bits) <= nhalf) ++bits;
+          size_t need = 0;
+          SMP_OK(hipcub::DeviceRadixSort::SortPairs(nullptr, need, keys0.as<unsigned>(), keys1.as<unsigned>(), idx0.as<int>(), idx1.as<int>(),
+                                                    (int)npool, 0, bits, 0));
+          SMP_MEM(sorttmp.reserve(need));
+          SMP_OK(hipcub::DeviceRadixSort::SortPairs(sorttmp.p, need, keys0.as<unsigned>(), keys1.as<unsigned>(), idx0.as<int>(), idx1.as<int>(),
+                                                    (int)npool, 0, bits, 0));
+        }
+        hipLaunchKernelGGL(smp_cand_kernel, dim3((unsigned)((ncand + 255) / 256)), dim3(256), 0, 0, (int)nhalf, calls->as<SmpBox>(), dim,
+                           (unsigned long long)sp->seed, (unsigned long long)pass, ninc, halves.as<SmpBox>(), cand.as<double>());
+        smp_eval(src, ncand, cand.as<double>());
+        hipLaunchKernelGGL(smp_stats_kernel, dim3((unsigned)nhalf), dim3(WAVE), 0, 0, (int)nhalf, npool, keys1.as<unsigned>(), idx1.as<int>(),
+                           pool.as<double>(), cand.as<double>(), halves.as<SmpBox>(), dim, nspec, ninc, tol, nadd.as<int>(), refine.as<int>(),
+                           addA.as<int>());
+        size_t need = 0;
+        SMP_OK(hipcub::DeviceScan::ExclusiveSum(nullptr, need, nadd.as<int>(), addoff.as<int>(), (int)nhalf, 0));
+        SMP_MEM(scantmp.reserve(need));
+        SMP_OK(hipcub::DeviceScan::ExclusiveSum(scantmp.p, need, nadd.as<int>(), addoff.as<int>(), (int)nhalf, 0));
+        SMP_OK(hipcub::DeviceScan::ExclusiveSum(scantmp.p, need, refine.as<int>(), childoff.as<int>(), (int)nhalf, 0));
+        int last[4];
+        SMP_OK(hipMemcpy(&last[0], addoff.as<int>() + nhalf - 1, 4, hipMemcpyDeviceToHost));
+        SMP_OK(hipMemcpy(&last[1], nadd.as<int>() + nhalf - 1, 4, hipMemcpyDeviceToHost));
+        SMP_OK(hipMemcpy(&last[2], childoff.as<int>() + nhalf - 1, 4, hipMemcpyDeviceToHost));
+        SMP_OK(hipMemcpy(&last[3], refine.as<int>() + nhalf - 1, 4, hipMemcpyDeviceToHost));
+        const long long total_add = (long long)last[0] + last[1], nchild = (long long)last[2] + last[3];
+        const int make_children = depth + 1 <= sp->max_recursion ? 1 : 0; // a call beyond maxdepth returns at once (:65-68)
+        if (npool + total_add >= (1ll << 31) - (1ll << 26)) return srt_set_error(SRT_EINVAL, "sample pool too large");
+        SMP_MEM(pool.reserve((size_t)(npool + total_add) * RB, (size_t)npool * RB));
+        SMP_MEM(slot.reserve((size_t)(npool + total_add) * sizeof(int), (size_t)npool * sizeof(int)));
+        SMP_MEM(children->reserve((size_t)(nchild > 0 ? nchild : 1) * sizeof(SmpBox)));
+        if (npool > 0)
+          hipLaunchKernelGGL(smp_reslot_kernel, dim3((unsigned)((npool + 255) / 256)), dim3(256), 0, 0, npool, keys0.as<unsigned>(),
+                             (unsigned)nhalf, refine.as<int>(), childoff.as<int>(), make_children, slot.as<int>());
+        hipLaunchKernelGGL(smp_commit_kernel, dim3((unsigned)((nhalf + 255) / 256)), dim3(256), 0, 0, (int)nhalf, ninc, addA.as<int>(),
+                           refine.as<int>(), addoff.as<int>(), childoff.as<int>(), make_children, cand.as<double>(), halves.as<SmpBox>(),
+                           npool, pool.as<double>(), slot.as<int>(), children->as<SmpBox>());
+        SMP_OK(hipDeviceSynchronize());
+        npool += total_add;
+        nsamples += total_add;
+        std::swap(calls, children);
+        ncalls = make_children ? nchild : 0;
+      }
+    }
+    counts[3] = nsamples;
+  }
+  // (4) zero altitude (:349-377), (5) ionosphere shell R_E .. R_E + 2000 km (:379-405): one draw each, kept when inside
+  if ((rc = run_stage(SMP_ZEROALT, sp->n_zero_altitude, R_E, R_E, false, counts[4]))) return rc;
+  if ((rc = run_stage(SMP_IRI, sp->n_iri_pad, R_E, R_E + 2000000.0, false, counts[5]))) return rc;
+
+  const size_t w = 3 + (size_t)nspec, ntail = tail.size() / w;
+  double *res = (double *)malloc(((size_t)npool + ntail + 1) * w * sizeof(double));
+  if (!res) return srt_set_error(SRT_ENOMEM, "malloc failed");
+  if (npool > 0) {
+    std::vector<double> h((size_t)npool * SMP_REC);
+    hipError_t e = hipMemcpy(h.data(), pool.p, h.size() * sizeof(double), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) {
+      free(res);
+      return srt_set_error(SRT_EDEVICE, "sample download: %s", hipGetErrorString(e));
+    }
+    for (long long i = 0; i < npool; ++i)
+      for (size_t c = 0; c < w; ++c) res[(size_t)i * w + c] = h[(size_t)i * SMP_REC + c];
+  }
+  if (ntail) memcpy(res + (size_t)npool * w, tail.data(), tail.size() * sizeof(double));
+  *out = res;
+  *n_out = npool + (int64_t)ntail;
+  if (stage_counts)
+    for (int q = 0; q < 6; ++q) stage_counts[q] = counts[q];
+  return SRT_OK;
+#undef SMP_OK
+#undef SMP_MEM
 }
 
 // ------------------------------------------------------------------------------------------ hot path

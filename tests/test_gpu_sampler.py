@@ -1,0 +1,111 @@
+"""GPU (-m gpu): the random / adaptive sample-set builder of SURVEY 8f-2 (gcpm_dens_model_buildgrid_random.f95 +
+randomsampling_mod.f95:recursivesampler with an in-scope model in place of GCPM), refined level by level on the device.
+Checked against the CPU oracle, which walks the recursion depth-first exactly as the reference does and draws from the
+same counter-based random numbers: the two must produce the same SET of samples."""
+import numpy as np
+import pytest
+
+from stanford_raytracer_amd import api, workloads as wl
+
+pytestmark = pytest.mark.gpu
+BOUNDS = np.array([-4.0, 4.0, -3.0, 3.5, -3.0, 3.0]) * wl.R_E
+KW = dict(n_zero_altitude=300, n_iri_pad=400, n_initial_radial=500, n_initial_uniform=700, adaptive_nmax=1500,
+          initial_tol=2.0, max_recursion=12, seed=20240611)
+
+
+def canon(a):
+    return a[np.lexsort((a[:, 2], a[:, 1], a[:, 0]))]
+
+
+@pytest.mark.parametrize("name", ["ngo", "interp"])
+def test_same_sample_set_as_the_depth_first_oracle(gpu_models, oracle_models, name):
+    g, o = gpu_models[name], oracle_models[name]
+    got, gc = g.build_samples(BOUNDS, **KW)
+    ref, rc = o.build_samples(BOUNDS, **KW)
+    assert gc == rc and gc[1] == 500 and gc[2] == 700 and gc[3] >= 1500
+    assert 0 < gc[4] <= 300 and 0 < gc[5] <= 400
+    assert got.shape == ref.shape == (sum(gc), 7)
+    # Stage blocks come in the reference's order.  Shell-stage positions pass through log/sqrt (util.f95:normal), whose
+    # device and host versions differ in the last bits; uniform and adaptive positions are products and sums only.
+    n1, n2, n3 = gc[1], gc[1] + gc[2], gc[1] + gc[2] + gc[3]
+    assert np.allclose(got[:n1, :3], ref[:n1, :3], rtol=1e-13, atol=1e-6)
+    assert np.array_equal(got[n1:n2, :3], ref[n1:n2, :3])
+    assert np.allclose(got[n3:, :3], ref[n3:, :3], rtol=1e-13, atol=1e-6)
+    # inside the adaptive block the device's order is by level, the oracle's depth-first: compare as sets
+    a, b = canon(got[n2:n3]), canon(ref[n2:n3])
+    assert np.array_equal(a[:, :3], b[:, :3])                 # bit-exact: every refinement decision agrees
+    for x, y in ((a, b), (got[:n2], ref[:n2]), (got[n3:], ref[n3:])):
+        fin = np.isfinite(y[:, 3:])
+        assert np.array_equal(np.isfinite(x[:, 3:]), fin)
+        assert np.abs(x[:, 3:][fin] - y[:, 3:][fin]).max() <= 1e-11   # ln N: the G0 bar of the density models
+
+
+def test_samples_are_the_models_own_values_and_seeded(gpu_models):
+    g = gpu_models["ngo"]
+    s1, c1 = g.build_samples(BOUNDS, **KW)
+    s2, _ = g.build_samples(BOUNDS, **KW)
+    assert np.array_equal(s1, s2, equal_nan=True)                             # a pure function of the seed
+    s3, _ = g.build_samples(BOUNDS, **dict(KW, seed=7))
+    assert not np.array_equal(s1[:50, :3], s3[:50, :3])
+    lo, hi = BOUNDS[0::2], BOUNDS[1::2]
+    assert np.all(s1[:, :3] > lo) and np.all(s1[:, :3] < hi)
+    with np.errstate(divide="ignore"):
+        want = np.log(g.plasma_params(s1[:, :3])[:, 4:8])
+    ok = np.isfinite(want)
+    assert np.abs(s1[:, 3:][ok] - want[ok]).max() <= 2e-14
+    r = np.linalg.norm(s1[:, :3], axis=1)
+    n0 = c1[1] + c1[2] + c1[3]
+    assert np.abs(r[n0:n0 + c1[4]] - wl.R_E).max() <= 1e-8 * wl.R_E               # zero-altitude stage
+    iri = r[n0 + c1[4]:]
+    assert iri.min() >= wl.R_E * (1 - 1e-12) and iri.max() <= wl.R_E + 2.0e6 * (1 + 1e-12)
+    assert np.all(r[:c1[1]] >= wl.R_E * (1 - 1e-12))                              # radial stage starts at R_E
+
+
+def test_refinement_goes_where_the_gradients_are(gpu_models):
+    """Adaptive samples concentrate where ln N varies: their median |grad ln Ne| is above the uniform stage's."""
+    g = gpu_models["ngo"]
+    s, c = g.build_samples(BOUNDS, n_initial_uniform=4000, adaptive_nmax=6000, initial_tol=1.0, max_recursion=18, seed=3)
+    uni, ada = s[:c[2]], s[c[2]:c[2] + c[3]]
+
+    def gradmag(P):
+        d = 1e3
+        with np.errstate(divide="ignore", invalid="ignore"):
+            gx = [(np.log(g.plasma_params(P + d * e)[:, 4]) - np.log(g.plasma_params(P - d * e)[:, 4])) / (2 * d)
+                  for e in np.eye(3)]
+        m = np.sqrt(sum(v * v for v in gx))
+        return m[np.isfinite(m)]
+
+    assert np.median(gradmag(ada[:, :3])) > 1.5 * np.median(gradmag(uni[:, :3]))
+
+
+def test_input_points_pass_through_and_scattered_round_trip(gpu_models, tmp_path):
+    """Existing points are kept in front (inputfile semantics, :210-227); the set is a valid model-4 file."""
+    g = gpu_models["ngo"]
+    first, c = g.build_samples(BOUNDS, n_initial_uniform=200, seed=11)
+    more, c2 = g.build_samples(BOUNDS, n_initial_uniform=3000, n_iri_pad=2000, adaptive_nmax=3000, initial_tol=1.0,
+                               max_recursion=15, seed=12, input_points=first)
+    assert c2[0] == 200 and np.array_equal(more[:200], first, equal_nan=True)
+    ok = np.all(np.isfinite(more), axis=1)
+    more = more[ok]
+    qs, ms = g.species()
+    path = str(tmp_path / "samples.txt")
+    wl.write_points_file(path, more[:, :3], more[:, 3:], BOUNDS, qs, ms)
+    m4 = api.Model.scattered_file(path, window_scale=1.5, order=1)
+    x = more[::37, :3] * (1 + 1e-9)
+    a, b = m4.plasma_params(x)[:, 4:8], g.plasma_params(x)[:, 4:8]
+    use = np.linalg.norm(x, axis=1) > wl.R_E + 3.0e6       # away from the ionosphere's steep gradients
+    rel = np.abs(np.log(a[use]) - np.log(b[use]))
+    assert np.median(rel) < 0.5
+
+
+def test_bad_requests_are_refused(gpu_models):
+    g = gpu_models["ngo"]
+    with pytest.raises(api.SrtError):
+        g.build_samples([1, 0, 0, 1, 0, 1])
+    # a box that holds 2e-7 of the radial shell's volume: the reference would spin in its `do while`; refused here
+    far = np.array([50, 51, 50, 51, 50, 51.0]) * wl.R_E
+    with pytest.raises(api.SrtError, match="radial stage"):
+        g.build_samples(far, n_initial_radial=5, seed=1)
+    inside = np.array([0.3, 0.4, 0.3, 0.4, 0.3, 0.4]) * wl.R_E       # no point of r >= R_E at all
+    with pytest.raises(api.SrtError, match="radial stage"):
+        g.build_samples(inside, n_initial_radial=1, seed=1)

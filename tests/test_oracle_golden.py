@@ -161,3 +161,29 @@ def test_g3_interp_self_sensitivity(golden, oracle_models):
     assert np.median(ex) <= bars["pos_median"] and ex.max() <= bars["pos_max"]
     assert np.median(ek) <= bars["k_median"] and np.percentile(ek, 90) <= bars["k_p90"] and ek.max() <= bars["k_max"]
     assert np.mean(ek <= 1e-7) >= bars["k_frac_tight"]
+
+
+def test_sampler_oracle_follows_the_reference_rules(oracle_models):
+    """srt_oracle_sampler.c (depth-first recursivesampler): stage counts, box membership, f(x) = log(Ns), determinism,
+    and refinement halves the tolerance until adaptive_nmax is passed (gcpm_dens_model_buildgrid_random.f95:330-345)."""
+    import numpy as np
+    R_E = 6371.2e3
+    o = oracle_models["ngo"]
+    b = np.array([-4.0, 4.0, -3.0, 3.5, -3.0, 3.0]) * R_E
+    kw = dict(n_zero_altitude=200, n_iri_pad=300, n_initial_radial=300, n_initial_uniform=400, adaptive_nmax=800,
+              initial_tol=2.0, max_recursion=10, seed=5)
+    s, c = o.build_samples(b, **kw)
+    s2, c2 = o.build_samples(b, **kw)
+    assert c == c2 and np.array_equal(s, s2, equal_nan=True)
+    assert c[0] == 0 and c[1] == 300 and c[2] == 400 and c[3] >= 800 and c[3] % 5 == 0
+    assert s.shape == (sum(c), 7)
+    assert np.all(s[:, :3] > b[0::2]) and np.all(s[:, :3] < b[1::2])
+    with np.errstate(divide="ignore"):
+        want = np.log(np.array([o.plasma_params(p)[1] for p in s[:50, :3]]))
+    assert np.array_equal(s[:50, 3:], want)
+    r = np.linalg.norm(s[:, :3], axis=1)
+    n0 = c[1] + c[2] + c[3]
+    assert np.abs(r[n0:n0 + c[4]] - R_E).max() < 1e-8 * R_E and r[n0 + c[4]:].max() <= R_E + 2.0e6 * (1 + 1e-12)
+    # a looser starting tolerance needs more passes but ends beyond adaptive_nmax all the same
+    s3, c3 = o.build_samples(b, **dict(kw, initial_tol=64.0))
+    assert c3[3] >= 800
