@@ -177,6 +177,34 @@ int srt_last_kernel_ms(srt_model *m, float *ms);
  * launches in flight on different streams read their durations afterwards */
 int srt_launch_ms(srt_model *m, int back, float *ms);
 
+/* ---- the step after the path: hot-plasma damping along the kept rows ----
+ * Replaces the MATLAB post-processor matlab/damping/: test_dampray.m:24-99 (per-row driver, running magnitude),
+ * spatialdamping.m / temporaldamping.m, hot_dispersion_imag.m (adaptive Gauss-Kronrod quadrature, quadva.m, of
+ * integrand.m over vperp), fG1.m, fG2.m, suprathermal.m, maxwellboltzmann.m.  It consumes exactly the columns a kept
+ * row holds (n, vgrel, pos, B0, Ns) plus the ray's w and the model's qs, ms; collisions are ignored as the scripts do.
+ * One hot species (electrons: qh = -1.60217646e-19 C, mh = 9.10938188e-31 kg, const.m). */
+typedef struct srt_damping_params {
+  int32_t dist;    /* 0: suprathermal.m (Bell 2002); 1: Ne_h * maxwellboltzmann(vperp,vpar,ME,kT) */
+  int32_t mode;    /* 0: spatial rate ki along vg (test_dampray.m); 1: temporal rate gamma (temporaldamping.m) */
+  int32_t nres;    /* number of resonances, 1..8; 0 = the script's m = [-1 0 1] */
+  int32_t m[8];    /* resonance orders (0 = Landau, +-1 = cyclotron) */
+  double Ne_h, kT; /* dist 1: hot density in m^-3, temperature in J */
+  double tol;      /* relative tolerance of the quadrature; 0 = the scripts' 1e-3 */
+} srt_damping_params;
+/* rows/nrows/w0 as returned by srt_trace_batch with the same slots = srt_rows_per_ray(p) and outputper.
+ * Outputs [nrays][slots]: rate (ki along vg in 1/m, or gamma in 1/s; 0 in slot 0), magnitude (1 in slot 0, then
+ * magnitude(i-1)*exp(-|pos_i - pos_{i-1}| ki_i) or *exp(gamma_i (t_i - t_{i-1})); 0 beyond the ray), flag (0 ok,
+ * 1 quadrature stopped before its error test was met, 2 integrand not finite (rate = NaN), 3 k = 0 (the scripts'
+ * "not solving evanescent mode": magnitude is 0 from there on)).  magnitude and flag may be NULL. */
+int srt_damping(const srt_damping_params *dp, int nspec, const double *qs, const double *ms, int32_t slots,
+                int32_t outputper, int64_t nrays, const double *rows, const int32_t *nrows, const double *w0,
+                double *rate, double *magnitude, int32_t *flag);
+/* the same on buffers already resident in device memory (the row buffer srt_trace_batch_device filled);
+ * d_magnitude may be NULL, d_flag may not.  Asynchronous on `stream`. */
+int srt_damping_device(const srt_damping_params *dp, int nspec, const double *qs, const double *ms, int32_t slots,
+                       int32_t outputper, int64_t nrays, const double *d_rows, const int32_t *d_nrows,
+                       const double *d_w0, double *d_rate, double *d_magnitude, int32_t *d_flag, void *stream);
+
 /* ---- file formats of the boundary ---- */
 /* ray input file: 7 list-directed reals per line (raytracer_driver.f95:1146); returns count, fills
  * malloc'd arrays the caller frees with srt_free */

@@ -11,7 +11,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "libsrt_oracle.so")
-SRCS = ["srt_oracle.c", "srt_oracle_scattered.c", "srt_oracle_sampler.c"]
+SRCS = ["srt_oracle.c", "srt_oracle_scattered.c", "srt_oracle_sampler.c", "srt_oracle_damping.c"]
 ROW = 20
 
 
@@ -23,6 +23,11 @@ def build(force=False):
     cmd = ["gcc", "-O2", "-ffp-contract=off", "-fno-fast-math", "-shared", "-fPIC", "-o", LIB, *srcs, "-lm", "-lpthread"]
     subprocess.check_call(cmd)
     return LIB
+
+
+class DampingParams(C.Structure):
+    _fields_ = [("dist", C.c_int), ("mode", C.c_int), ("nres", C.c_int), ("m", C.c_int * 8), ("Ne_h", C.c_double),
+                ("kT", C.c_double), ("tol", C.c_double)]
 
 
 class Params(C.Structure):
@@ -74,6 +79,9 @@ def lib():
         L.so_build_samples.argtypes = [C.c_void_p, dp, lp, C.c_double, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_long, dp,
                                        lp, lp]
         L.so_free.argtypes = [C.c_void_p]
+        L.sod_damping.argtypes = [C.POINTER(DampingParams), C.c_int, dp, dp, C.c_int, C.c_int, C.c_long, dp, ip, dp, dp, dp, ip]
+        L.sod_quadva_test.restype = C.c_double
+        L.sod_quadva_test.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, ip, dp, ip]
         L.so_dipole_tilt.argtypes = [C.c_int, C.c_int, dp]
         L.so_speed_of_light.restype = C.c_double
         _lib = L
@@ -223,3 +231,31 @@ def dipole_tilt(yearday, msec):
     v = C.c_double()
     lib().so_dipole_tilt(yearday, msec, C.byref(v))
     return v.value
+
+
+def damping_params(dist=0, mode=0, m=(), Ne_h=0.0, kT=0.0, tol=0.0):
+    p = DampingParams()
+    p.dist, p.mode, p.nres, p.Ne_h, p.kT, p.tol = dist, mode, len(m), Ne_h, kT, tol
+    for i, v in enumerate(m):
+        p.m[i] = int(v)
+    return p
+
+
+def damping(qs, ms, outputper, rows, nrows, w0, **kw):
+    """matlab/damping restated (srt_oracle_damping.c): rows [nrays, slots, 20] -> rate, magnitude, flag [nrays, slots]."""
+    rows = _arr(rows)
+    nrays, slots, _ = rows.shape
+    nrows = np.ascontiguousarray(nrows, dtype=np.int32)
+    qs, ms, w0 = _arr(qs), _arr(ms), _arr(w0, nrays)
+    rate, mag = np.zeros((nrays, slots)), np.zeros((nrays, slots))
+    flag = np.zeros((nrays, slots), dtype=np.int32)
+    p = damping_params(**kw)
+    lib().sod_damping(C.byref(p), qs.size, _dp(qs), _dp(ms), slots, outputper, nrays, _dp(rows), _ip(nrows), _dp(w0),
+                      _dp(rate), _dp(mag), _ip(flag))
+    return rate, mag, flag
+
+
+def quadva_test(kind, a, b, reltol, abstol):
+    ok, nev, err = C.c_int(), C.c_int(), C.c_double()
+    v = lib().sod_quadva_test(kind, a, b, reltol, abstol, C.byref(ok), C.byref(err), C.byref(nev))
+    return v, bool(ok.value), err.value, nev.value

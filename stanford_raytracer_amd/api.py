@@ -48,6 +48,12 @@ class SamplerParams(C.Structure):
                 ("max_passes", C.c_int32), ("reserved", C.c_int32), ("seed", C.c_uint64)]
 
 
+class DampingParams(C.Structure):
+    """srt_damping_params of include/srt.h."""
+    _fields_ = [("dist", C.c_int32), ("mode", C.c_int32), ("nres", C.c_int32), ("m", C.c_int32 * 8),
+                ("Ne_h", C.c_double), ("kT", C.c_double), ("tol", C.c_double)]
+
+
 def library_path():
     return _build.LIB
 
@@ -102,6 +108,10 @@ def lib():
                                                      C.POINTER(vp)]
     L.srt_build_samples.argtypes = [vp, C.POINTER(SamplerParams), C.c_int64, dp, C.POINTER(C.c_int64), C.POINTER(dp),
                                     C.POINTER(C.c_int64)]
+    L.srt_damping.argtypes = [C.POINTER(DampingParams), C.c_int, dp, dp, C.c_int32, C.c_int32, C.c_int64, dp, ip, dp, dp,
+                              dp, ip]
+    L.srt_damping_device.argtypes = [C.POINTER(DampingParams), C.c_int, dp, dp, C.c_int32, C.c_int32, C.c_int64, vp, vp,
+                                     vp, vp, vp, vp, vp]
     i32p = C.POINTER(C.c_int32)
     L.srt_grid_file_read.argtypes = [C.c_char_p, i32p, dp, dp, dp, C.POINTER(dp), C.POINTER(dp)]
     L.srt_grid_file_write.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, dp, dp, dp, dp, dp]
@@ -300,6 +310,30 @@ class Model:
         ms = C.c_float()
         _check(lib().srt_last_kernel_ms(self.h, C.byref(ms)))
         return ms.value
+
+
+def damping_params(dist=0, mode=0, m=(), Ne_h=0.0, kT=0.0, tol=0.0):
+    p = DampingParams()
+    p.dist, p.mode, p.nres, p.Ne_h, p.kT, p.tol = dist, mode, len(m), Ne_h, kT, tol
+    for i, v in enumerate(m):
+        p.m[i] = int(v)
+    return p
+
+
+def damping(species, outputper, rows, nrows, w0, **kw):
+    """Hot-plasma damping along the kept rows (the reference's matlab/damping post-processor, on the device).
+    rows [nrays, slots, 20], nrows [nrays], w0 [nrays] as Model.trace returns them -> rate, magnitude, flag."""
+    qs, ms = species
+    rows = _f64(rows)
+    nrays, slots, _ = rows.shape
+    nrows = np.ascontiguousarray(nrows, dtype=np.int32)
+    qs, ms, w0 = _f64(qs), _f64(ms), _f64(w0, (nrays,))
+    rate, mag = np.zeros((nrays, slots)), np.zeros((nrays, slots))
+    flag = np.zeros((nrays, slots), dtype=np.int32)
+    p = damping_params(**kw)
+    _check(lib().srt_damping(C.byref(p), qs.size, _dp(qs), _dp(ms), slots, outputper, nrays, _dp(rows),
+                             nrows.ctypes.data_as(ip), _dp(w0), _dp(rate), _dp(mag), flag.ctypes.data_as(ip)))
+    return rate, mag, flag
 
 
 def is_right_handed(rows):

@@ -16,6 +16,7 @@
 #include "srt_kernels.hpp"
 #include "srt_scattered.hpp"
 #include "srt_sampler.hpp"
+#include "srt_damping.hpp"
 #include <hipcub/hipcub.hpp>
 #include "tricubic_matrix.h"
 
@@ -1160,6 +1161,87 @@ extern "C" int srt_last_kernel_ms(srt_model *m, float *ms) {
   srt_model::LaunchSlot &sl = m->slot[m->last_slot];
   HIP_OK(hipEventSynchronize(sl.ev1));
   HIP_OK(hipEventElapsedTime(ms, sl.ev0, sl.ev1));
+  return SRT_OK;
+}
+
+
+// ---- the step after the path: hot-plasma damping along the kept rows (kernels: srt_damping.hpp) ----
+extern "C" int srt_damping_device(const srt_damping_params *dp, int nspec, const double *qs, const double *ms, int32_t slots,
+                                  int32_t outputper, int64_t nrays, const double *d_rows, const int32_t *d_nrows,
+                                  const double *d_w0, double *d_rate, double *d_magnitude, int32_t *d_flag, void *stream) {
+  if (!dp || !qs || !ms || !d_rows || !d_nrows || !d_w0 || !d_rate || !d_flag || nrays < 0)
+    return srt_set_error(SRT_EINVAL, "bad argument");
+  if (nspec < 1 || nspec > SRT_MAXSPEC) return srt_set_error(SRT_EINVAL, "nspec=%d unsupported", nspec);
+  if (slots < 1 || outputper < 1) return srt_set_error(SRT_EINVAL, "slots and outputper must be >= 1");
+  if (dp->dist != 0 && dp->dist != 1) return srt_set_error(SRT_EINVAL, "dist must be 0 (suprathermal) or 1 (Maxwell-Boltzmann)");
+  if (dp->mode != 0 && dp->mode != 1) return srt_set_error(SRT_EINVAL, "mode must be 0 (spatial) or 1 (temporal)");
+  if (dp->nres < 0 || dp->nres > DMP_MAXRES) return srt_set_error(SRT_EINVAL, "nres out of range (0..%d)", DMP_MAXRES);
+  if (dp->dist == 1 && (!(dp->kT > 0.0) || !(dp->Ne_h >= 0.0))) return srt_set_error(SRT_EINVAL, "Maxwell-Boltzmann needs kT > 0 and Ne_h >= 0");
+  if (!(dp->tol >= 0.0)) return srt_set_error(SRT_EINVAL, "tol must be >= 0");
+  int rc = ensure_init();
+  if (rc) return rc;
+  if (nrays == 0) return SRT_OK;
+  if (nrays * (long long)slots >= (1ll << 40)) return srt_set_error(SRT_EINVAL, "too many rows");
+  DampArgs a;
+  a.rows = d_rows;
+  a.nrows = d_nrows;
+  a.w0 = d_w0;
+  a.nrays = nrays;
+  a.slots = slots;
+  a.outputper = outputper;
+  a.nspec = nspec;
+  for (int s = 0; s < MAXSPEC; ++s) {
+    a.q[s] = s < nspec ? qs[s] : 0.0;
+    a.ms[s] = s < nspec ? ms[s] : 1.0;
+  }
+  a.p.dist = dp->dist;
+  a.p.mode = dp->mode;
+  a.p.nres = dp->nres ? dp->nres : 3;
+  for (int i = 0; i < DMP_MAXRES; ++i) a.p.m[i] = dp->nres ? dp->m[i] : (i < 3 ? i - 1 : 0);
+  for (int i = 0; i < a.p.nres; ++i)
+    if (a.p.m[i] < -16 || a.p.m[i] > 16) return srt_set_error(SRT_EINVAL, "resonance order %d out of range", a.p.m[i]);
+  a.p.Ne_h = dp->Ne_h;
+  a.p.kT = dp->kT;
+  a.p.tol = dp->tol > 0.0 ? dp->tol : 1e-3;
+  a.p.qh = -1.60217646e-19; // const.m
+  a.p.mh = 9.10938188e-31;
+  a.rate = d_rate;
+  a.flag = d_flag;
+  hipStream_t st = (hipStream_t)stream;
+  const long long total = nrays * slots;
+  const long long grid = total < (1ll << 30) ? total : (1ll << 30);
+  hipLaunchKernelGGL(damping_rate_kernel, dim3((unsigned)grid), dim3(WAVE), 0, st, a);
+  if (d_magnitude) hipLaunchKernelGGL(damping_magnitude_kernel, dim3((unsigned)((nrays + 63) / 64)), dim3(64), 0, st, a, d_magnitude);
+  HIP_OK(hipGetLastError());
+  return SRT_OK;
+}
+
+extern "C" int srt_damping(const srt_damping_params *dp, int nspec, const double *qs, const double *ms, int32_t slots,
+                           int32_t outputper, int64_t nrays, const double *rows, const int32_t *nrows, const double *w0,
+                           double *rate, double *magnitude, int32_t *flag) {
+  if (!rows || !nrows || !w0 || !rate || nrays < 0 || slots < 1) return srt_set_error(SRT_EINVAL, "bad argument");
+  int rc = ensure_init();
+  if (rc) return rc;
+  if (nrays == 0) return SRT_OK;
+  const size_t nr = (size_t)nrays * slots;
+  DevBuf d_rows, d_w0, d_rate, d_mag;
+  int *d_nrows = nullptr, *d_flag = nullptr;
+  if ((rc = upload(d_rows, rows, nr * SRT_ROW)) || (rc = upload(d_w0, w0, nrays))) return rc;
+  if (d_rate.alloc(nr) || d_mag.alloc(nr)) return srt_set_error(SRT_ENOMEM, "hipMalloc failed");
+  hipError_t e = hipMalloc(&d_nrows, nrays * sizeof(int));
+  if (e == hipSuccess) e = hipMalloc(&d_flag, nr * sizeof(int));
+  if (e == hipSuccess) e = hipMemcpy(d_nrows, nrows, nrays * sizeof(int), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    rc = srt_damping_device(dp, nspec, qs, ms, slots, outputper, nrays, d_rows.p, d_nrows, d_w0.p, d_rate.p, d_mag.p, d_flag, nullptr);
+    if (!rc) e = hipDeviceSynchronize();
+    if (!rc && e == hipSuccess) e = hipMemcpy(rate, d_rate.p, nr * sizeof(double), hipMemcpyDeviceToHost);
+    if (!rc && e == hipSuccess && magnitude) e = hipMemcpy(magnitude, d_mag.p, nr * sizeof(double), hipMemcpyDeviceToHost);
+    if (!rc && e == hipSuccess && flag) e = hipMemcpy(flag, d_flag, nr * sizeof(int), hipMemcpyDeviceToHost);
+  }
+  if (d_nrows) (void)hipFree(d_nrows);
+  if (d_flag) (void)hipFree(d_flag);
+  if (rc) return rc;
+  if (e != hipSuccess) return srt_set_error(SRT_EDEVICE, "damping: %s", hipGetErrorString(e));
   return SRT_OK;
 }
 
