@@ -51,6 +51,8 @@ def parse_args():
     ap.add_argument("--points", type=int, default=0, help="override sample count (scattered)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline sample duration (0=skip)")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--damping-rays", type=int, default=100_000,
+                    help="rays whose kept rows get the damping post-pass after the timed region (N=1 only; 0 = skip)")
     ap.add_argument("--refill", type=int, default=0)
     ap.add_argument("--streams", type=int, default=2, help="HIP streams the steps alternate on (1 = strictly serial)")
     ap.add_argument("--ray-order", type=int, default=1, choices=[0, 1],
@@ -279,6 +281,8 @@ def main():
                        "stopcond_hist": {str(int(k)): int(v) for k, v in zip(*np.unique(stop, return_counts=True))},
                        "model_setup_s": setup_s, "model_device_GB": model.device_bytes / 1e9},
         }
+        if args.damping_rays > 0 and world == 1:
+            out["detail"]["damping"] = damping_leg(args, api, model, p, slots, d_rows, d_nrows, d_w, dev, torch, nrows)
         out["cpu_baseline"] = cpu_baseline(args, kind, p, wl, pos0, dir0, w0, grid_n) if (args.cpu_seconds > 0 and world == 1) else None
         # the real reference (Fortran, one core -- its only mode), when its prebuilt harness travelled with the repo
         out["cpu_reference"] = cpu_reference(args, kind, p, wl, pos0, dir0, w0) if (args.cpu_seconds > 0 and world == 1) else None
@@ -286,6 +290,54 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def damping_leg(args, api, model, p, slots, d_rows, d_nrows, d_w, dev, torch, nrows):
+    """The step after the path, outside the timed region: hot-plasma damping (suprathermal electrons,
+    m = -1, 0, 1, tol 1e-3: test_dampray.m's settings) along the kept rows of the first --damping-rays rays, straight
+    from the row buffer the last launch left in HBM; the CPU oracle's restatement of the MATLAB scripts beside it."""
+    import ctypes as C
+    n = int(min(args.damping_rays, d_rows.shape[0]))
+    qs, ms = model.species()
+    d_rate = torch.empty((n, slots), dtype=torch.float64, device=dev)
+    d_mag = torch.empty_like(d_rate)
+    d_flag = torch.empty((n, slots), dtype=torch.int32, device=dev)
+    dp = api.damping_params()
+    st = torch.cuda.current_stream(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(dev)
+    e0.record(st)
+    rc = api.lib().srt_damping_device(C.byref(dp), len(qs), api._dp(api._f64(qs)), api._dp(api._f64(ms)), slots, p.outputper, n,
+                                      d_rows.data_ptr(), d_nrows.data_ptr(), d_w.data_ptr(), d_rate.data_ptr(),
+                                      d_mag.data_ptr(), d_flag.data_ptr(), st.cuda_stream)
+    if rc != 0:
+        return {"error": api.lib().srt_last_error().decode()}
+    e1.record(st)
+    torch.cuda.synchronize(dev)
+    ms_gpu = e0.elapsed_time(e1)
+    kept = (np.maximum(nrows[:n], 1) - 1) // p.outputper + 1
+    nrow_eval = int((kept - 1).sum())
+    flag = d_flag.cpu().numpy()
+    out = {"rays": n, "rows_evaluated": nrow_eval, "kernel_ms": ms_gpu, "rows_per_s": nrow_eval / (ms_gpu * 1e-3),
+           "flags": {str(int(k)): int(v) for k, v in zip(*np.unique(flag, return_counts=True))},
+           "final_magnitude_median": float(np.nanmedian(d_mag.cpu().numpy()[np.arange(n), kept - 1]))}
+    if args.cpu_seconds > 0:
+        try:
+            from oracle import oracle
+            nc = int(min(n, 24))
+            rows_h = d_rows[:nc].cpu().numpy()
+            t0 = time.time()
+            rk, _, _ = oracle.damping(qs, ms, p.outputper, rows_h, nrows[:nc], d_w[:nc].cpu().numpy())
+            dt = time.time() - t0
+            ne = int((kept[:nc] - 1).sum())
+            g = d_rate[:nc].cpu().numpy()
+            ok = np.isfinite(rk) & np.isfinite(g) & (rk != 0)
+            out["cpu_port"] = {"rows_per_s": ne / max(dt, 1e-9), "cores": 1, "rows": ne,
+                               "max_rel_diff_vs_gpu": float(np.max(np.abs(g[ok] - rk[ok]) / np.abs(rk[ok]))) if ok.any() else None,
+                               "median_rel_diff_vs_gpu": float(np.median(np.abs(g[ok] - rk[ok]) / np.abs(rk[ok]))) if ok.any() else None}
+        except Exception as e:  # pragma: no cover
+            out["cpu_port"] = {"error": str(e)}
+    return out
 
 
 def cpu_baseline(args, kind, p, wl, pos0, dir0, w0, grid_n):
