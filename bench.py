@@ -50,6 +50,7 @@ def parse_args():
     ap.add_argument("--maxsteps", type=int, default=0)
     ap.add_argument("--points", type=int, default=0, help="override sample count (scattered)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline sample duration (0=skip)")
+    ap.add_argument("--use-igrf", type=int, default=0, choices=[0, 1], help="IGRF main field instead of the dipole (driver flag --use_igrf)")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--damping-rays", type=int, default=100_000,
                     help="rays whose kept rows get the damping post-pass after the timed region (N=1 only; 0 = skip)")
@@ -140,6 +141,9 @@ def main():
         setup_s = time.time() - t0
         wname = "%d rays/GPU, ngo_dens_model, dipole B, adaptive RK45" % nrays
 
+    if args.use_igrf:
+        model.set_field(use_igrf=1)
+        wname += ", IGRF main field"
     pos0, dir0, w0 = wl.launch_set(nrays, seed + 1000 * rank)
     p.ray_order = args.ray_order
     slots = api.lib().srt_rows_per_ray(p)
@@ -360,6 +364,8 @@ def cpu_baseline(args, kind, p, wl, pos0, dir0, w0, grid_n):
         with open(cfg, "w") as f:
             f.write(wl.NEWRAY_PLASMAPAUSE)
         om = oracle.Model.ngo(cfg)
+    if args.use_igrf:
+        om.set_igrf()
     setup = time.time() - t0
     kw = dict(dt0=p.dt0, dtmax=p.dtmax, tmax=p.tmax, maxerr=p.maxerr, minalt=p.minalt, del_=p.del_,
               maxsteps=p.maxsteps, root=p.root, fixedstep=p.fixedstep)
@@ -389,19 +395,20 @@ def cpu_reference(args, kind, p, wl, pos0, dir0, w0):
         return {"error": "refharness unavailable: %s" % e}
     if not refharness.available() or kind == "scattered":
         return None
+    igrf = {"use_igrf": 1} if args.use_igrf else {}
     td = tempfile.mkdtemp()
     if kind == "interp":
         gn = 64
         F, bounds = wl.make_grid(gn, half_width=10.0 * wl.R_E)
         gfile = os.path.join(td, "grid64.txt")
         wl.write_grid_file(gfile, F, bounds)
-        model = {"kind": 3, "file": gfile}
+        model = dict({"kind": 3, "file": gfile}, **igrf)
         note = "interp model on a %d^3 text grid of the same plasmasphere" % gn
     else:
         cfg = os.path.join(td, "newray.in")
         with open(cfg, "w") as f:
             f.write(wl.NEWRAY_PLASMAPAUSE)
-        model = {"kind": 1, "file": cfg}
+        model = dict({"kind": 1, "file": cfg}, **igrf)
         note = "ngo model"
     kw = dict(dt0=p.dt0, dtmax=p.dtmax, tmax=p.tmax, maxerr=p.maxerr, minalt=p.minalt, maxsteps=p.maxsteps,
               root=p.root, fixedstep=p.fixedstep)

@@ -11,7 +11,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "libsrt_oracle.so")
-SRCS = ["srt_oracle.c", "srt_oracle_scattered.c", "srt_oracle_sampler.c", "srt_oracle_damping.c"]
+SRCS = ["srt_oracle.c", "srt_oracle_scattered.c", "srt_oracle_sampler.c", "srt_oracle_damping.c", "srt_oracle_igrf.c"]
 ROW = 20
 
 
@@ -56,6 +56,7 @@ def lib():
         L.so_model_create_scattered_file.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int,
                                                      C.c_double, C.c_uint]
         L.so_model_destroy.argtypes = [C.c_void_p]
+        L.so_model_set_igrf.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p]
         L.so_model_nspec.argtypes = [C.c_void_p]
         L.so_plasma_params.argtypes = [C.c_void_p, dp, dp, dp, dp, dp, dp]
         L.so_dispersion_relation.restype = C.c_double
@@ -131,6 +132,13 @@ class Model:
                        local_window_scale=5.0, perm_seed=1):
         return cls(lib().so_model_create_scattered_file(os.fsencode(ptsfile), yearday, msec, window_scale, order,
                                                         exact, local_window_scale, perm_seed))
+
+    def set_igrf(self, yearday=2010001, msec=0, coeff_file=None):
+        """use_igrf = 1 for this model."""
+        path = coeff_file or os.path.join(os.path.dirname(HERE), "stanford_raytracer_amd", "data", "igrf_coeffs.txt")
+        if lib().so_model_set_igrf(self.h, yearday, msec, os.fsencode(path)) != 0:
+            raise RuntimeError("IGRF coefficient table unreadable: %s" % path)
+        return self
 
     def __del__(self):
         try:

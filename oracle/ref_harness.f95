@@ -72,6 +72,17 @@ program ref_harness
      itime(2) = floor(tmpinput)
   end if
 
+  call getopt_named('use_igrf', buffer, foundopt)
+  if (foundopt == 1) then
+     read(buffer,*) tmpinput
+     use_igrf = floor(tmpinput)
+  end if
+  call getopt_named('use_tsyganenko', buffer, foundopt)
+  if (foundopt == 1) then
+     read(buffer,*) tmpinput
+     use_tsy = floor(tmpinput)
+  end if
+
   if (trim(mode) == 'rh') then
      call do_rh()
      stop

@@ -25,6 +25,10 @@ def _model_flags(model):
     kind = model["kind"]
     fl = ["--modelnum=%d" % kind, "--yearday=%d" % model.get("yearday", 2010001),
           "--milliseconds_day=%d" % model.get("msec", 0)]
+    if model.get("use_igrf"):
+        fl.append("--use_igrf=1")
+    if model.get("use_tsyganenko"):
+        fl.append("--use_tsyganenko=1")
     if kind == 1:
         fl.append("--ngo_configfile=%s" % model["file"])
     else:

@@ -176,13 +176,22 @@ void so_dipole_tilt(int yearday, int msec, double *mu) {
  * scattered_..:283-370) with use_igrf = use_tsyganenko = 0. */
 void so_bfield(so_model *m, const double x[3], double B0[3]) {
   double Bsm[3], Bgsm[3], Bt[3];
-  bmodel_cartesian(x, Bsm);
-  /* SM_TO_GSM_d: t4_d(..., -1) => rotate_y(-mu) */
-  rotate_y(-1 * m->mu, Bsm, Bgsm);
+  float base[3];
+  if (m->use_igrf) {
+    /* IGRF_GSM(real(x_gsm/R_E)), x_gsm = SM_TO_GSM_d(itime, x)   (interp_dens_model_adapter.f95:186,236-241) */
+    double xg[3];
+    rotate_y(-1 * m->mu, x, xg);
+    so_igrf_gsw(m->igrf_G, m->igrf_H, m->igrf_REC, m->igrf_A, (float)(xg[0] / R_E), (float)(xg[1] / R_E), (float)(xg[2] / R_E),
+                &base[0], &base[1], &base[2]);
+  } else {
+    bmodel_cartesian(x, Bsm);
+    /* SM_TO_GSM_d: t4_d(..., -1) => rotate_y(-mu) */
+    rotate_y(-1 * m->mu, Bsm, Bgsm);
+    for (int i = 0; i < 3; i++) base[i] = (float)(1.0e9 * Bgsm[i]); /* B0xBASE = real(1.0e9_DP*B0tmp2(1)) */
+  }
   for (int i = 0; i < 3; i++) {
-    float base = (float)(1.0e9 * Bgsm[i]); /* B0xBASE = real(1.0e9_DP*B0tmp2(1)) */
     float tsy = 0.0f;
-    Bt[i] = (double)(base + tsy) * 1.0e-9;
+    Bt[i] = (double)(base[i] + tsy) * 1.0e-9;
   }
   /* GSM_TO_SM_d: rotate_y(+mu) */
   rotate_y(1 * m->mu, Bt, B0);

@@ -43,6 +43,9 @@ so_model *so_model_create_interp(int nspec, int nx, int ny, int nz, const double
 so_model *so_model_create_scattered_file(const char *ptsfile, int yearday, int msec,
                                          double window_scale, int order, int exact,
                                          double local_window_scale, unsigned perm_seed);
+/* use_igrf = 1 (interp_dens_model_adapter.f95:236-241): IGRF via geopack's RECALC_08 / IGRF_GSW_08 restated in
+ * srt_oracle_igrf.c; coeff_file = the Gauss-coefficient table (stanford_raytracer_amd/data/igrf_coeffs.txt). */
+int so_model_set_igrf(so_model *m, int yearday, int msec, const char *coeff_file);
 void so_model_destroy(so_model *m);
 int so_model_nspec(const so_model *m);
 int so_model_kind(const so_model *m); /* 1 ngo, 3 interp, 4 scattered */

@@ -48,11 +48,15 @@ struct so_scattered {
 struct so_model {
   int kind, nspec;
   double mu; /* dipole tilt (T4.f95) */
+  int use_igrf; /* srt_oracle_igrf.c */
+  float igrf_G[105], igrf_H[105], igrf_REC[105], igrf_A[9];
   so_ngo ngo;
   so_grid grid;
   struct so_scattered *sc;
 };
 
+void so_igrf_gsw(const float *G, const float *H, const float *REC, const float A[9], float xgsw, float ygsw, float zgsw, float *hx,
+                 float *hy, float *hz);
 void so_cartesian_to_spherical(const double x[3], double p[3]);
 void so_scattered_params(struct so_model *m, const double x[3], double qs[4], double Ns[4],
                          double ms[4], double nus[4]);

@@ -79,6 +79,7 @@ def lib():
                                                           C.POINTER(vp)]
     L.srt_model_create_scattered_file.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int,
                                                   C.c_double, C.POINTER(vp)]
+    L.srt_model_set_field.argtypes = [vp, C.c_int, C.c_int, C.c_char_p]
     L.srt_model_destroy.argtypes = [vp]
     L.srt_model_destroy.restype = None
     L.srt_model_kind.argtypes = [vp]
@@ -236,6 +237,12 @@ class Model:
         _check(lib().srt_model_create_interp_from_model(self.h, int(bool(compder)), nx, ny, nz,
                                                         _dp(_f64(bounds, (6,))), yearday, msec, C.byref(h)))
         return Model(h)
+
+    def set_field(self, use_igrf=0, use_tsyganenko=0, igrf_coeff_file=None):
+        """--use_igrf / --use_tsyganenko of the driver (Tsyganenko is not built and is refused)."""
+        _check(lib().srt_model_set_field(self.h, int(use_igrf), int(use_tsyganenko),
+                                         os.fsencode(igrf_coeff_file) if igrf_coeff_file else None))
+        return self
 
     def close(self):
         if self.h:

@@ -114,6 +114,8 @@ static void fill_common(Common &cm, int nspec, const double *qs, const double *m
   cm.sp.minm_eps0 = minm * EPS0;
   const double MU0 = PI * 4e-7; // constants.f95:6
   cm.C = sqrt(1.0 / EPS0 / MU0); // constants.f95:7
+  cm.fld.yearday = yearday;
+  cm.fld.msec = msec;
   double mu = srt_host::dipole_tilt(yearday, msec);
   cm.fld.cm = cos(mu);
   cm.fld.sm = sin(mu);
@@ -160,6 +162,34 @@ extern "C" void srt_model_destroy(srt_model *m) {
   }
   if (m->d_common) (void)hipFree(m->d_common);
   delete m;
+}
+// use_igrf (raytracer_driver.f95 --use_igrf; interp_dens_model_adapter.f95:236-241 and twins)
+#include <dlfcn.h>
+extern "C" int srt_model_set_field(srt_model *m, int use_igrf, int use_tsyganenko, const char *igrf_coeff_file) {
+  if (!m) return srt_set_error(SRT_EINVAL, "null model");
+  if (use_tsyganenko) return srt_set_error(SRT_EINVAL, "use_tsyganenko=1 (T04_s external field) is not built");
+  if (use_igrf != 0 && use_igrf != 1) return srt_set_error(SRT_EINVAL, "use_igrf must be 0 or 1");
+  int rc = ensure_init();
+  if (rc) return rc;
+  FieldConst &f = m->cm.fld;
+  if (use_igrf) {
+    std::string path;
+    if (igrf_coeff_file && *igrf_coeff_file) path = igrf_coeff_file;
+    else if (const char *e = getenv("SRT_IGRF_COEFFS")) path = e;
+    else { // the table shipped beside the library: <pkg>/lib/libsrt_hip.so -> <pkg>/data/igrf_coeffs.txt
+      Dl_info info;
+      if (dladdr((const void *)&srt_model_set_field, &info) && info.dli_fname) {
+        path = info.dli_fname;
+        size_t k = path.rfind('/');
+        path = (k == std::string::npos ? std::string(".") : path.substr(0, k)) + "/../data/igrf_coeffs.txt";
+      }
+    }
+    std::string err;
+    if (!srt_host::igrf_setup(path.c_str(), f.yearday, f.msec, f.G, f.H, f.REC, f.A, err)) return srt_set_error(SRT_EIO, "%s", err.c_str());
+  }
+  f.use_igrf = use_igrf;
+  HIP_OK(hipMemcpy(m->d_common, &m->cm, sizeof(Common), hipMemcpyHostToDevice));
+  return SRT_OK;
 }
 extern "C" int srt_model_kind(const srt_model *m) { return m ? m->kind : 0; }
 extern "C" int srt_model_nspec(const srt_model *m) { return m ? m->nspec : 0; }

@@ -67,8 +67,8 @@ int main(int argc, char **argv) {
          "  --dt0 --dtmax --tmax --root --fixedstep --maxerr --maxsteps --minalt\n"
          "  --inputraysfile --outputfile --outputper\n"
          "  --modelnum  (1) Ngo model  (3) interpolated model (gridded)  (4) interpolated model (scattered)\n"
-         "  model 1: --ngo_configfile --yearday --milliseconds_day --use_tsyganenko=0 --use_igrf=0\n"
-         "  model 3: --interp_interpfile --yearday --milliseconds_day --use_tsyganenko=0 --use_igrf=0\n"
+         "  model 1: --ngo_configfile --yearday --milliseconds_day --use_tsyganenko=0 --use_igrf=0|1\n"
+         "  model 3: --interp_interpfile --yearday --milliseconds_day --use_tsyganenko=0 --use_igrf=0|1\n"
          "  model 4: model 3 flags + --scattered_interp_window_scale --scattered_interp_order\n"
          "           --scattered_interp_exact --scattered_interp_local_window_scale\n"
          "  extra:   --device=N  --first_attempt_policy=0|1  --chunk_rays=N  --ray_order=0|1\n"
@@ -115,8 +115,8 @@ int main(int argc, char **argv) {
   need(get_int("milliseconds_day", msec), "milliseconds_day");
   get_int("use_tsyganenko", use_tsy);
   get_int("use_igrf", use_igrf);
-  if (use_tsy != 0 || use_igrf != 0) {
-    fprintf(stderr, "raytracer: --use_tsyganenko=1 / --use_igrf=1 are outside the accelerated path (dipole B only)\n");
+  if (use_tsy != 0) {
+    fprintf(stderr, "raytracer: --use_tsyganenko=1 (T04_s external field) is outside the accelerated path\n");
     return 2;
   }
   CHECK(srt_init(device));
@@ -145,6 +145,11 @@ int main(int argc, char **argv) {
   } else {
     fprintf(stderr, "raytracer: --modelnum=%d is not on the accelerated path (1, 3, 4 are)\n", modelnum);
     return 2;
+  }
+  if (use_igrf != 0) {
+    std::string coeffs;
+    getopt_named("igrf_coeffs", coeffs); // ours: table of Gauss coefficients (default: shipped beside the library)
+    CHECK(srt_model_set_field(m, 1, 0, coeffs.empty() ? nullptr : coeffs.c_str()));
   }
   double *pos0 = nullptr, *dir0 = nullptr, *w0 = nullptr;
   int64_t nrays = srt_read_rays_file(rays_path.c_str(), &pos0, &dir0, &w0);

@@ -32,6 +32,10 @@ struct Species {
 struct FieldConst {
   double bo_re3; // Bo * R_E^3, Bo = .312/10000 T
   double cm, sm; // cos(mu), sin(mu), mu = dipole tilt for the run's itime
+  // use_igrf = 1 (interp_dens_model_adapter.f95:236-241): Schmidt-normalised Gauss coefficients for the run's date,
+  // recursion constants and the GEO->GSM matrix, as RECALC_08 leaves them (host: srt_host::igrf_setup)
+  int use_igrf, yearday, msec, pad_;
+  float G[105], H[105], REC[105], A[9];
 };
 
 struct Common {
@@ -54,10 +58,93 @@ __device__ __forceinline__ double fdiv(double a, double b) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// IGRF_GSM -> IGRF_GSW_08 (geopack2008.for:55-185, GEOGSW_08 :1421-1457): spherical-harmonic synthesis of the main
+// field at a GSM position in Earth radii, nT, default REAL (fp32) like the Fortran.  The expansion is truncated at a
+// degree that falls with distance (NM = 3 + 30/int(r+2), at most 13); the loops run to the wave's largest degree with
+// per-lane predicates, so the coefficient index is wave-uniform and G/H/REC come through scalar loads.  The Fortran's
+// A(N), B(N) arrays are the running products r^-(n+1) and n r^-(n+1): carried in registers, same multiplication chain.
+__device__ __noinline__ void igrf_gsm(const FieldConst &f, float xg, float yg, float zg, float &hx, float &hy, float &hz) {
+#pragma clang fp contract(off)
+  const float xgeo = f.A[0] * xg + f.A[3] * yg + f.A[6] * zg;
+  const float ygeo = f.A[1] * xg + f.A[4] * yg + f.A[7] * zg;
+  const float zgeo = f.A[2] * xg + f.A[5] * yg + f.A[8] * zg;
+  const float rho2 = xgeo * xgeo + ygeo * ygeo;
+  const float r = sqrtf(rho2 + zgeo * zgeo);
+  const float c = zgeo / r;
+  const float rho = sqrtf(rho2);
+  const float s = rho / r;
+  const bool pole = s < 1.e-5f;
+  const float cf = pole ? 1.f : xgeo / rho, sf = pole ? 0.f : ygeo / rho;
+  const float pp = 1.f / r;
+  const int irp3 = (int)(r + 2.f);
+  int nm = 3 + 30 / (irp3 < 1 ? 1 : irp3);
+  if (nm > 13) nm = 13;
+  const int k = nm + 1;
+  int kmax = k;
+  for (int off = 32; off > 0; off >>= 1) {
+    const int o = __shfl_xor(kmax, off, 64);
+    kmax = o > kmax ? o : kmax;
+  }
+  kmax = __builtin_amdgcn_readfirstlane(kmax);
+  float p = 1.f, d = 0.f, bbr = 0.f, bbt = 0.f, bbf = 0.f, x = 0.f, y = 1.f;
+  float am = pp * pp; // A(m) = pp^(m+1)
+  for (int m = 1; m <= kmax; ++m) {
+    if (m <= k) {
+      if (m > 1) {
+        const float w = x;
+        x = w * cf + y * sf;
+        y = y * cf - w * sf;
+      }
+      float q = p, z = d, bi = 0.f, p2 = 0.f, d2 = 0.f, an = am;
+      for (int n = m; n <= kmax; ++n) {
+        const int mn = n * (n - 1) / 2 + m - 1;
+        const float e = f.G[mn], hh = f.H[mn], xk = f.REC[mn];
+        if (n <= k) {
+          const float w = e * y + hh * x;
+          bbr = bbr + (an * (float)n) * w * q;
+          bbt = bbt - an * w * z;
+          if (m != 1) bi = bi + an * (e * x - hh * y) * (pole ? z : q);
+          const float dp = c * z - s * q - xk * d2;
+          const float pm = c * q - xk * p2;
+          d2 = z;
+          p2 = q;
+          z = dp;
+          q = pm;
+          an = an * pp;
+        }
+      }
+      d = s * d + c * p;
+      p = s * p;
+      if (m != 1) bbf = bbf + bi * (float)(m - 1);
+      am = am * pp;
+    }
+  }
+  float bf;
+  if (pole) bf = c < 0.f ? -bbf : bbf;
+  else bf = bbf / s;
+  const float he = bbr * s + bbt * c;
+  const float hxgeo = he * cf - bf * sf, hygeo = he * sf + bf * cf, hzgeo = bbr * c - bbt * s;
+  hx = f.A[0] * hxgeo + f.A[1] * hygeo + f.A[2] * hzgeo;
+  hy = f.A[3] * hxgeo + f.A[4] * hygeo + f.A[5] * hzgeo;
+  hz = f.A[6] * hxgeo + f.A[7] * hygeo + f.A[8] * hzgeo;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Dipole B in SM coordinates, then the adapters' GSM round trip through float32 nT
 // (bmodel_dipole.f95:20-48; interp_dens_model_adapter.f95:243-267 and its twins; SURVEY A-8).
 // Trig-free form: B = Bo R_E^3 / r^5 * (-3xz, -3yz, x^2 + y^2 - 2 z^2).
 __device__ __forceinline__ void bfield(const FieldConst &f, double x, double y, double z, double B[3]) {
+  if (f.use_igrf) { // wave-uniform
+    // x_gsm = SM_TO_GSM_d(x); IGRF_GSM(real(x_gsm/R_E)) in nT; (B + 0)*1e-9; GSM_TO_SM_d
+    const double xg = x * f.cm - z * f.sm, zg = z * f.cm + x * f.sm;
+    float hx, hy, hz;
+    igrf_gsm(f, (float)(xg / R_E), (float)(y / R_E), (float)(zg / R_E), hx, hy, hz);
+    const double gx = (double)(hx + 0.0f) * 1.0e-9, gy = (double)(hy + 0.0f) * 1.0e-9, gz = (double)(hz + 0.0f) * 1.0e-9;
+    B[0] = gx * f.cm + gz * f.sm;
+    B[1] = gy;
+    B[2] = gz * f.cm - gx * f.sm;
+    return;
+  }
   double rho2 = x * x + y * y;
   double r2 = rho2 + z * z;
   double r = sqrt(r2);

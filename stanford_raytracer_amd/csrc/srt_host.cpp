@@ -52,6 +52,143 @@ double dipole_tilt(int yearday, int msec) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// IGRF set-up for one date (host, once per model): what RECALC_08 leaves in COMMON /GEOPACK1/ and /GEOPACK2/ that
+// IGRF_GSW_08 reads.  Everything is default REAL in the Fortran, so everything is float here; SUN_08's two DOUBLE
+// PRECISION variables are double (geopack2008.for:333-381, :486-1196).
+namespace {
+struct SunAngles {
+  float gst = 0.f, srasn = 0.f, sdec = 0.f;
+};
+SunAngles sun_angles(int iyear, int iday, int ihour, int min, int isec) {
+  SunAngles o;
+  const float RAD = 57.295779513f;
+  if (iyear < 1901 || iyear > 2099) return o;
+  const double fday = (double)(ihour * 3600 + min * 60 + isec) / 86400.0;
+  const double dj = 365 * (iyear - 1900) + (iyear - 1901) / 4 + iday - 0.5 + fday;
+  const float t = (float)(dj / (double)36525.f);
+  const float vl = (float)std::fmod((double)279.696678f + (double)0.9856473354f * dj, 360.0);
+  o.gst = (float)(std::fmod((double)279.690983f + (double).9856473354f * dj + (double)360.f * fday + (double)180.f, 360.0) / (double)RAD);
+  const float g = (float)(std::fmod((double)358.475845f + (double)0.985600267f * dj, 360.0) / (double)RAD);
+  float slong = (vl + (1.91946f - 0.004789f * t) * sinf(g) + 0.020094f * sinf(2.f * g)) / RAD;
+  if (slong > 6.2831853f) slong = slong - 6.2831853f;
+  if (slong < 0.f) slong = slong + 6.2831853f;
+  const float obliq = (23.45229f - 0.0130125f * t) / RAD;
+  const float sob = sinf(obliq), slp = slong - 9.924e-5f;
+  const float sind = sob * sinf(slp);
+  const float cosd = sqrtf(1.f - sind * sind);
+  const float sc = sind / cosd;
+  o.sdec = atanf(sc);
+  o.srasn = 3.141592654f - atan2f(cosf(obliq) / sob * sc, -cosf(slp) / cosd);
+  return o;
+}
+} // namespace
+
+bool igrf_setup(const char *coeff_file, int yearday, int msec, float G[105], float H[105], float REC[105], float A[9],
+                std::string &err) {
+  // table: "g|h mn v1965 v1970 ... v2020 sv"
+  static const int NEP = 12;
+  std::vector<float> tg(13 * 105, 0.f), th(13 * 105, 0.f);
+  FILE *f = fopen(coeff_file, "r");
+  if (!f) {
+    err = std::string("cannot open IGRF coefficient table ") + coeff_file;
+    return false;
+  }
+  char line[2048];
+  int seen = 0;
+  while (fgets(line, sizeof line, f)) {
+    if (line[0] != 'g' && line[0] != 'h') continue;
+    char *s = line + 1;
+    const long mn = strtol(s, &s, 10);
+    if (mn < 1 || mn > 105) continue;
+    for (int e = 0; e <= NEP; ++e) (line[0] == 'g' ? tg : th)[e * 105 + (mn - 1)] = strtof(s, &s);
+    ++seen;
+  }
+  fclose(f);
+  if (seen != 210) {
+    err = std::string("IGRF coefficient table has the wrong number of rows: ") + coeff_file;
+    return false;
+  }
+  // itime -> calendar fields as the adapters do (interp_dens_model_adapter.f95:217-221)
+  const int iyear = yearday / 1000, iday = yearday % 1000;
+  const int ihour = msec / (1000 * 60 * 60);
+  const int min = (msec - ihour * (1000 * 60 * 60)) / (1000 * 60);
+  const int isec = (msec - ihour * (1000 * 60 * 60) - min * (1000 * 60)) / 1000;
+  int iy = iyear < 1965 ? 1965 : iyear > 2025 ? 2025 : iyear;
+  for (int n = 1; n <= 14; ++n) {
+    const int n2 = (2 * n - 1) * (2 * n - 3);
+    for (int m = 1; m <= n; ++m) REC[n * (n - 1) / 2 + m - 1] = (float)((n - m) * (n + m - 2)) / (float)n2;
+  }
+  const float yfrac = (float)iy + (float)(iday - 1) / 365.25f;
+  if (iy >= 2020) { // extrapolate: secular variation for degrees <= 8 (the first 45 entries)
+    const float dt = yfrac - 2020.f;
+    for (int n = 0; n < 105; ++n) {
+      G[n] = tg[11 * 105 + n];
+      H[n] = th[11 * 105 + n];
+      if (n < 45) {
+        G[n] = G[n] + tg[12 * 105 + n] * dt;
+        H[n] = H[n] + th[12 * 105 + n] * dt;
+      }
+    }
+  } else { // interpolate between the two bracketing epochs
+    const int e = (iy - 1965) / 5;
+    const float f2 = (yfrac - (float)(1965 + 5 * e)) / 5.f, f1 = 1.f - f2;
+    for (int n = 0; n < 105; ++n) {
+      G[n] = tg[e * 105 + n] * f1 + tg[(e + 1) * 105 + n] * f2;
+      H[n] = th[e * 105 + n] * f1 + th[(e + 1) * 105 + n] * f2;
+    }
+  }
+  // Gauss -> Schmidt quasi-normalised
+  float s = 1.f;
+  for (int n = 2; n <= 14; ++n) {
+    const int mn = n * (n - 1) / 2 + 1;
+    s = s * (float)(2 * n - 3) / (float)(n - 1);
+    G[mn - 1] = G[mn - 1] * s;
+    H[mn - 1] = H[mn - 1] * s;
+    float p = s;
+    for (int m = 2; m <= n; ++m) {
+      const float aa = m == 2 ? 2.f : 1.f;
+      p = p * sqrtf(aa * (float)(n - m + 1) / (float)(n + m - 2));
+      G[mn + m - 2] = G[mn + m - 2] * p;
+      H[mn + m - 2] = H[mn + m - 2] * p;
+    }
+  }
+  // dipole axis in GEO, Sun direction, GSE/GSW axes, GEO -> GSW rotation
+  const float g10 = -G[1], g11 = G[2], h11 = H[2];
+  const float sq = g11 * g11 + h11 * h11, sqq = sqrtf(sq), sqr = sqrtf(g10 * g10 + sq);
+  const float sl0 = -h11 / sqq, cl0 = -g11 / sqq, st0 = sqq / sqr, ct0 = g10 / sqr;
+  const float stcl = st0 * cl0, stsl = st0 * sl0;
+  const SunAngles sun = sun_angles(iy, iday, ihour, min, isec);
+  const float s1 = cosf(sun.srasn) * cosf(sun.sdec), s2 = sinf(sun.srasn) * cosf(sun.sdec), s3 = sinf(sun.sdec);
+  const float dj = (float)(365 * (iy - 1900) + (iy - 1901) / 4 + iday) - 0.5f + (float)(ihour * 3600 + min * 60 + isec) / 86400.f;
+  const float t = dj / 36525.f;
+  const float obliq = (23.45229f - 0.0130125f * t) / 57.2957795f;
+  const float dz1 = 0.f, dz2 = -sinf(obliq), dz3 = cosf(obliq);
+  const float dy1 = dz2 * s3 - dz3 * s2, dy2 = dz3 * s1 - dz1 * s3, dy3 = dz1 * s2 - dz2 * s1;
+  const float vx = -400.f, vy = 0.f, vz = 0.f; // tsy_recalc's solar wind: GSW coincides with GSM
+  const float v = sqrtf(vx * vx + vy * vy + vz * vz);
+  const float dx1 = -vx / v, dx2 = -vy / v, dx3 = -vz / v;
+  const float x1 = dx1 * s1 + dx2 * dy1 + dx3 * dz1, x2 = dx1 * s2 + dx2 * dy2 + dx3 * dz2, x3 = dx1 * s3 + dx2 * dy3 + dx3 * dz3;
+  const float cgst = cosf(sun.gst), sgst = sinf(sun.gst);
+  const float dip1 = stcl * cgst - stsl * sgst, dip2 = stcl * sgst + stsl * cgst, dip3 = ct0;
+  float y1 = dip2 * x3 - dip3 * x2, y2 = dip3 * x1 - dip1 * x3, y3 = dip1 * x2 - dip2 * x1;
+  const float y = sqrtf(y1 * y1 + y2 * y2 + y3 * y3);
+  y1 = y1 / y;
+  y2 = y2 / y;
+  y3 = y3 / y;
+  const float z1 = x2 * y3 - x3 * y2, z2 = x3 * y1 - x1 * y3, z3 = x1 * y2 - x2 * y1;
+  A[0] = x1 * cgst + x2 * sgst;
+  A[1] = -x1 * sgst + x2 * cgst;
+  A[2] = x3;
+  A[3] = y1 * cgst + y2 * sgst;
+  A[4] = -y1 * sgst + y2 * cgst;
+  A[5] = y3;
+  A[6] = z1 * cgst + z2 * sgst;
+  A[7] = -z1 * sgst + z2 * cgst;
+  A[8] = z3;
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------
 ListReader::ListReader(const char *path) : f_(fopen(path, "r")), line_(1 << 16) {}
 ListReader::~ListReader() {
   if (f_) fclose((FILE *)f_);

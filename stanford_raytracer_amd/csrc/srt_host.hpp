@@ -8,6 +8,11 @@ namespace srt_host {
 
 // dipole tilt angle mu of xform_double/T4.f95:7-18 for itime = (yearday, msec)
 double dipole_tilt(int yearday, int msec);
+// use_igrf = 1: Gauss coefficients for the run's date, Schmidt-normalised, the recursion constants and the GEO->GSM
+// matrix (geopack2008.for RECALC_08 + SUN_08 with V_sw = (-400,0,0), i.e. tsy_recalc of geopack0508_adapter.for:21-30),
+// default REAL arithmetic like the Fortran.  coeff_file = table of IAGA coefficients (data/igrf_coeffs.txt).
+bool igrf_setup(const char *coeff_file, int yearday, int msec, float G[105], float H[105], float REC[105], float A[9],
+                std::string &err);
 
 // newray.in card file (ngo_dens_model.f95:45-118; field names per matlab/unused/parse_newray_cards.m)
 struct NgoConfig {

@@ -65,9 +65,29 @@ def test_cli_rejects_out_of_scope_requests(tmp_path, cfgfiles):
     base = [os.path.join(BIN, "raytracer"), "--dt0=1e-3", "--tmax=0.01", "--root=2", "--fixedstep=1", "--maxsteps=10",
             "--minalt=6.4712e6", "--inputraysfile=%s" % rf, "--outputfile=%s" % (tmp_path / "o.ray"), "--yearday=2010001",
             "--milliseconds_day=0", "--ngo_configfile=%s" % cfgfiles["ngo"]]
-    assert subprocess.run(base + ["--modelnum=1", "--use_igrf=1"]).returncode == 2
+    assert subprocess.run(base + ["--modelnum=1", "--use_tsyganenko=1"]).returncode == 2
     assert subprocess.run(base + ["--modelnum=2"]).returncode == 2
     assert subprocess.run(base + ["--modelnum=1"]).returncode == 0
+
+
+def test_cli_use_igrf(tmp_path, cfgfiles):
+    """--use_igrf=1: the .ray rows carry the IGRF field of the library's own evaluation; an unreadable
+    coefficient table is an error, not a silent dipole."""
+    from stanford_raytracer_amd import api
+    rf = tmp_path / "rays.txt"
+    rf.write_text("7e6 0 0 1 0 0 1e4\n")
+    out = tmp_path / "o.ray"
+    base = [os.path.join(BIN, "raytracer"), "--dt0=1e-3", "--tmax=0.01", "--root=2", "--fixedstep=1", "--maxsteps=10",
+            "--minalt=6.4712e6", "--inputraysfile=%s" % rf, "--outputfile=%s" % out, "--yearday=2010001",
+            "--milliseconds_day=0", "--ngo_configfile=%s" % cfgfiles["ngo"], "--modelnum=1", "--use_igrf=1"]
+    assert subprocess.run(base).returncode == 0
+    row0 = [float(v) for v in out.read_text().splitlines()[0].split()]
+    api.init(0)
+    want = api.Model.ngo(cfgfiles["ngo"]).set_field(use_igrf=1).plasma_params([[7e6, 0, 0]])[0, 16:19]
+    dip = api.Model.ngo(cfgfiles["ngo"]).plasma_params([[7e6, 0, 0]])[0, 16:19]
+    got = np.array(row0[15:18])
+    assert np.allclose(got, want, rtol=1e-14, atol=0) and not np.allclose(got, dip, rtol=1e-3)
+    assert subprocess.run(base + ["--igrf_coeffs=/nonexistent"]).returncode != 0
 
 
 def test_binary_grid_is_the_same_model(tmp_path, grid16):

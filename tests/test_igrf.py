@@ -1,0 +1,98 @@
+"""use_igrf = 1 (IGRF half): the adapters' field tail with geopack's IGRF in place of the dipole.
+CPU: the oracle's restatement (oracle/srt_oracle_igrf.c) against goldens captured from the reference itself.
+GPU: the device evaluation against the same goldens and the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_DIR
+from stanford_raytracer_amd import workloads as wl
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(os.path.join(GOLDEN_DIR, "igrf_golden.npz"))
+
+
+def test_oracle_igrf_is_bit_identical_to_the_reference(gold, cfgfiles):
+    from oracle import oracle
+    x = gold["x"]
+    for i, (yd, ms) in enumerate(gold["dates"]):
+        o = oracle.Model.ngo(cfgfiles["ngo"], int(yd), int(ms)).set_igrf(int(yd), int(ms))
+        mine = np.array([o.plasma_params(p)[4] for p in x])
+        assert np.array_equal(mine, gold["B_%d" % i]), "date %d" % i
+    # IGRF differs from the centred dipole by tens of percent near the Earth and converges to it far out
+    o = oracle.Model.ngo(cfgfiles["ngo"], 2010001, 0)
+    dip = np.array([o.plasma_params(p)[4] for p in x])
+    r = np.linalg.norm(x, axis=1) / wl.R_E
+    rel = np.linalg.norm(gold["B_0"] - dip, axis=1) / np.linalg.norm(dip, axis=1)
+    assert rel[r < 1.5].max() > 0.1 and np.median(rel[r > 6]) < np.median(rel[r < 2])
+
+
+def test_oracle_igrf_trajectories_match_the_reference(gold, cfgfiles):
+    from oracle import oracle
+    yd, ms = (int(v) for v in gold["dates"][0])
+    o = oracle.Model.ngo(cfgfiles["ngo"], yd, ms).set_igrf(yd, ms)
+    rows, nrows, stop, _ = o.trace(gold["run_pos0"], gold["run_dir0"], gold["run_w0"], dt0=1e-3, dtmax=0.1, maxerr=5e-4,
+                                   maxsteps=60, minalt=wl.MINALT, tmax=0.05, fixedstep=1, del_=1e-4)
+    assert np.array_equal(nrows, gold["run_nrows"]) and np.array_equal(stop, gold["run_stop"])
+    T = gold["run_rows"].shape[1]
+    assert np.array_equal(rows[:, :T], gold["run_rows"])
+
+
+def test_coefficient_table_is_complete():
+    from stanford_raytracer_amd import build
+    path = os.path.join(build.PKG, "data", "igrf_coeffs.txt")
+    rows = [ln.split() for ln in open(path) if ln[:1] in "gh"]
+    assert len(rows) == 210 and all(len(r) == 15 for r in rows)
+    g10 = [r for r in rows if r[0] == "g" and r[1] == "2"][0]
+    assert float(g10[2]) == -30334.0 and float(g10[13]) == -29404.8      # g(1,0) of DGRF-1965 and IGRF-13 2020
+
+
+@pytest.mark.gpu
+def test_gpu_igrf_field_matches_reference_goldens(gold, cfgfiles, grid16):
+    from stanford_raytracer_amd import api
+    api.init(0)
+    x = gold["x"]
+    F, b, qs, ms_ = grid16
+    for i, (yd, ms) in enumerate(gold["dates"]):
+        want = gold["B_%d" % i]
+        for m in (api.Model.ngo(cfgfiles["ngo"], int(yd), int(ms)), api.Model.interp(F, b, qs, ms_, yearday=int(yd), msec=int(ms))):
+            m.set_field(use_igrf=1)
+            got = m.plasma_params(x)[:, 16:19]
+            # fp32 synthesis: the device rounds like the Fortran except where its double-precision rotation of the
+            # position contracts to an FMA before the cast to float
+            err = np.abs(got - want).max(axis=1) / np.linalg.norm(want, axis=1)
+            assert err.max() <= 2e-6, (i, err.max())
+            assert np.mean(err <= 1e-14) >= 0.9      # same fp32 synthesis; the fp64 rotations differ in the last bit
+            m.set_field(use_igrf=0)
+            dip = m.plasma_params(x)[:, 16:19]
+            assert np.abs(dip - want).max() > 0       # and back to the dipole
+    with pytest.raises(api.SrtError):
+        api.Model.ngo(cfgfiles["ngo"]).set_field(use_tsyganenko=1)
+    with pytest.raises(api.SrtError):
+        api.Model.ngo(cfgfiles["ngo"]).set_field(use_igrf=1, igrf_coeff_file="/nonexistent/table.txt")
+
+
+@pytest.mark.gpu
+def test_gpu_igrf_trajectories(gold, cfgfiles):
+    """Fixed-step Ngo rays in the IGRF field against the reference's rows (same bars as the dipole ladder, G4)."""
+    from stanford_raytracer_amd import api
+    api.init(0)
+    yd, ms = (int(v) for v in gold["dates"][0])
+    m = api.Model.ngo(cfgfiles["ngo"], yd, ms).set_field(use_igrf=1)
+    p = api.make_params(dt0=1e-3, dtmax=0.1, maxerr=5e-4, maxsteps=60, minalt=wl.MINALT, tmax=0.05, fixedstep=1, del_=1e-4)
+    rows, nrows, stop, _ = m.trace(gold["run_pos0"], gold["run_dir0"], gold["run_w0"], params=p)
+    assert np.array_equal(nrows, gold["run_nrows"]) and np.array_equal(stop, gold["run_stop"])
+    ref = gold["run_rows"]
+    for r in range(ref.shape[0]):
+        T = nrows[r]
+        pos_err = np.linalg.norm(rows[r, :T, 1:4] - ref[r, :T, 1:4], axis=1) / np.linalg.norm(ref[r, :T, 1:4], axis=1)
+        # The whole field is an fp32 number here, so dF/dx (central difference, del = 1e-4 relative) sees a staircase
+        # of relative height 1e-7/1e-4: one ulp32 of difference in B moves the k-derivative by 1e-3 (SURVEY A-8, only
+        # more so than with the dipole, whose staircase comes from the final cast alone).  First step tight, then the
+        # drift the reference itself shows under a 1-ulp32 perturbation of B.
+        assert pos_err[1] <= 1e-8 and pos_err.max() <= 5e-3
+        B_err = np.linalg.norm(rows[r, :T, 13:16] - ref[r, :T, 13:16], axis=1) / np.linalg.norm(ref[r, :T, 13:16], axis=1)
+        assert B_err[0] <= 2e-6 and B_err.max() <= 5e-3
