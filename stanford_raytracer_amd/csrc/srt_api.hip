@@ -185,7 +185,15 @@ extern "C" int srt_model_set_field(srt_model *m, int use_igrf, int use_tsyganenk
       }
     }
     std::string err;
-    if (!srt_host::igrf_setup(path.c_str(), f.yearday, f.msec, f.G, f.H, f.REC, f.A, err)) return srt_set_error(SRT_EIO, "%s", err.c_str());
+    float G[105], H[105], REC[105];
+    if (!srt_host::igrf_setup(path.c_str(), f.yearday, f.msec, G, H, REC, f.A, err)) return srt_set_error(SRT_EIO, "%s", err.c_str());
+    for (int mm = 1; mm <= 14; ++mm)
+      for (int n = mm; n <= 14; ++n) { // geopack's index n(n-1)/2 + m  ->  visiting order
+        const int mn = n * (n - 1) / 2 + mm - 1, e = igrf_off(mm) + n - mm;
+        f.Gv[e] = G[mn];
+        f.Hv[e] = H[mn];
+        f.Rv[e] = REC[mn];
+      }
   }
   f.use_igrf = use_igrf;
   HIP_OK(hipMemcpy(m->d_common, &m->cm, sizeof(Common), hipMemcpyHostToDevice));
@@ -1154,19 +1162,22 @@ extern "C" int srt_trace_batch_device(srt_model *m, const srt_params *p, int64_t
     HIP_OK(hipcub::DeviceRadixSort::SortPairs(sl.d_sorttmp, tb, sl.d_keys[0], sl.d_keys[1], sl.d_ids[0], sl.d_ids[1], (int)nrays, 0, 30, st));
     a.order = sl.d_ids[1];
   }
-  bool fixed = p->fixedstep != 0;
-  if (m->kind == 1) {
-    if (fixed) hipLaunchKernelGGL((trace_kernel<NgoModel, true, false>), dim3((unsigned)grid), dim3(WAVE), 0, st, (const NgoModel *)m->d_model, (const Common *)m->d_common, a);
-    else hipLaunchKernelGGL((trace_kernel<NgoModel, false, false>), dim3((unsigned)grid), dim3(WAVE), 0, st, (const NgoModel *)m->d_model, (const Common *)m->d_common, a);
-  } else if (m->kind == 3) {
-    if (fixed) hipLaunchKernelGGL((trace_kernel<InterpModel, true, true>), dim3((unsigned)grid), dim3(WAVE), 0, st, (const InterpModel *)m->d_model, (const Common *)m->d_common, a);
-    else hipLaunchKernelGGL((trace_kernel<InterpModel, false, true>), dim3((unsigned)grid), dim3(WAVE), 0, st, (const InterpModel *)m->d_model, (const Common *)m->d_common, a);
-  } else if (m->kind == 4) {
-    if (fixed) hipLaunchKernelGGL((trace_kernel<ScatteredModel, true, true>), dim3((unsigned)grid), dim3(WAVE), 0, st, (const ScatteredModel *)m->d_model, (const Common *)m->d_common, a);
-    else hipLaunchKernelGGL((trace_kernel<ScatteredModel, false, true>), dim3((unsigned)grid), dim3(WAVE), 0, st, (const ScatteredModel *)m->d_model, (const Common *)m->d_common, a);
-  } else {
-    return srt_set_error(SRT_EINVAL, "model kind %d unsupported", m->kind);
-  }
+  const bool fixed = p->fixedstep != 0, igrf = m->cm.fld.use_igrf != 0;
+  // one instantiation per (model, integrator, field option): the dipole kernels carry none of the IGRF code
+#define SRT_LAUNCH_TRACE(MODEL, LDS)                                                                                             \
+  do {                                                                                                                           \
+    const MODEL *dm = (const MODEL *)m->d_model;                                                                                 \
+    const Common *dc = (const Common *)m->d_common;                                                                              \
+    if (fixed && igrf) hipLaunchKernelGGL((trace_kernel<MODEL, true, LDS, true>), dim3((unsigned)grid), dim3(WAVE), 0, st, dm, dc, a);        \
+    else if (fixed) hipLaunchKernelGGL((trace_kernel<MODEL, true, LDS, false>), dim3((unsigned)grid), dim3(WAVE), 0, st, dm, dc, a);          \
+    else if (igrf) hipLaunchKernelGGL((trace_kernel<MODEL, false, LDS, true>), dim3((unsigned)grid), dim3(WAVE), 0, st, dm, dc, a);           \
+    else hipLaunchKernelGGL((trace_kernel<MODEL, false, LDS, false>), dim3((unsigned)grid), dim3(WAVE), 0, st, dm, dc, a);                    \
+  } while (0)
+  if (m->kind == 1) SRT_LAUNCH_TRACE(NgoModel, false);
+  else if (m->kind == 3) SRT_LAUNCH_TRACE(InterpModel, true);
+  else if (m->kind == 4) SRT_LAUNCH_TRACE(ScatteredModel, true);
+  else return srt_set_error(SRT_EINVAL, "model kind %d unsupported", m->kind);
+#undef SRT_LAUNCH_TRACE
   HIP_OK(hipGetLastError());
   HIP_OK(hipEventRecord(sl.ev1, st));
   sl.used = true;

@@ -7,6 +7,7 @@
 // dF/dw, trigonometry in the dipole field) are evaluated once, and divisions are merged.  Results
 // differ from the reference at rounding level only; the parity ladder in DESIGN.md bounds that.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -35,14 +36,29 @@ struct FieldConst {
   // use_igrf = 1 (interp_dens_model_adapter.f95:236-241): Schmidt-normalised Gauss coefficients for the run's date,
   // recursion constants and the GEO->GSM matrix, as RECALC_08 leaves them (host: srt_host::igrf_setup)
   int use_igrf, yearday, msec, pad_;
-  float G[105], H[105], REC[105], A[9];
+  // g, h, rec per (m, n) term in the ORDER THE SYNTHESIS VISITS THEM (m = 1..14 outer, n = m..14 inner): entry
+  // (m, n) sits at igrf_off(m) + n - m.  Padded to 128: lane l of a wave keeps entries l and l + 64 in registers.
+  float Gv[128], Hv[128], Rv[128];
+  float A[9];
 };
+__host__ __device__ inline int igrf_off(int m) { return (m - 1) * 15 - (m - 1) * m / 2; }
 
 struct Common {
   Species sp;
   FieldConst fld;
   double C; // speed of light as constants.f95:7 computes it
 };
+// The same constants with the field option fixed at compile time: the trace kernel is instantiated once per option, so
+// that the dipole kernel carries none of the IGRF synthesis' registers or code (sharing one kernel cost it 11 %).
+// Plain `Common` means "look at fld.use_igrf at run time" (the layered kernels).
+struct CommonDipole : Common {};
+struct CommonIgrf : Common {};
+template <class CM>
+__device__ __forceinline__ bool field_is_igrf(const CM &cm) {
+  if constexpr (std::is_same<CM, CommonDipole>::value) return false;
+  else if constexpr (std::is_same<CM, CommonIgrf>::value) return true;
+  else return cm.fld.use_igrf != 0;
+}
 
 // a/b for operands well inside the exponent range (every division of the hot path: frequencies, densities,
 // field magnitudes, grid spacings).  This is the compiler's own fp64 division sequence -- v_rcp_f64, two Newton
@@ -59,90 +75,155 @@ __device__ __forceinline__ double fdiv(double a, double b) {
 
 // ---------------------------------------------------------------------------------------------
 // IGRF_GSM -> IGRF_GSW_08 (geopack2008.for:55-185, GEOGSW_08 :1421-1457): spherical-harmonic synthesis of the main
-// field at a GSM position in Earth radii, nT, default REAL (fp32) like the Fortran.  The expansion is truncated at a
-// degree that falls with distance (NM = 3 + 30/int(r+2), at most 13); the loops run to the wave's largest degree with
-// per-lane predicates, so the coefficient index is wave-uniform and G/H/REC come through scalar loads.  The Fortran's
-// A(N), B(N) arrays are the running products r^-(n+1) and n r^-(n+1): carried in registers, same multiplication chain.
-__device__ __noinline__ void igrf_gsm(const FieldConst &f, float xg, float yg, float zg, float &hx, float &hy, float &hz) {
+// field at GSM positions in Earth radii, nT, default REAL (fp32) like the Fortran, for NP points per lane at once.
+//  * The expansion is truncated at a degree that falls with distance (NM = 3 + 30/int(r+2), at most 13); the loops run
+//    to the wave's largest degree with per-point predicates, so the term index is wave-uniform.
+//  * The 105 (g, h, rec) terms live in six registers spread over the wave (lane l: terms l and l + 64 in visiting
+//    order), loaded by two coalesced reads per call; term i is a v_readlane with a uniform lane number: no memory
+//    access and no wait inside the loops (a load per term -- scalar or vector -- stalls the wave once per term).
+//  * One point per call is a 105-step chain of dependent fp32 operations with one wave per SIMD to hide it behind:
+//    the seven stencil points of a right-hand side are therefore synthesised together (independent chains).
+//  * The Fortran's A(N), B(N) arrays are the running products r^-(n+1), n r^-(n+1): registers, same multiplication chain.
+template <int NP>
+__device__ __forceinline__ void igrf_core(const FieldConst &f, const float (&xg)[NP], const float (&yg)[NP], const float (&zg)[NP],
+                                          float (&hx)[NP], float (&hy)[NP], float (&hz)[NP]) {
 #pragma clang fp contract(off)
-  const float xgeo = f.A[0] * xg + f.A[3] * yg + f.A[6] * zg;
-  const float ygeo = f.A[1] * xg + f.A[4] * yg + f.A[7] * zg;
-  const float zgeo = f.A[2] * xg + f.A[5] * yg + f.A[8] * zg;
-  const float rho2 = xgeo * xgeo + ygeo * ygeo;
-  const float r = sqrtf(rho2 + zgeo * zgeo);
-  const float c = zgeo / r;
-  const float rho = sqrtf(rho2);
-  const float s = rho / r;
-  const bool pole = s < 1.e-5f;
-  const float cf = pole ? 1.f : xgeo / rho, sf = pole ? 0.f : ygeo / rho;
-  const float pp = 1.f / r;
-  const int irp3 = (int)(r + 2.f);
-  int nm = 3 + 30 / (irp3 < 1 ? 1 : irp3);
-  if (nm > 13) nm = 13;
-  const int k = nm + 1;
-  int kmax = k;
+  const int lane = (int)__lane_id();
+  const int g0 = __builtin_bit_cast(int, f.Gv[lane]), g1 = __builtin_bit_cast(int, f.Gv[lane + 64]);
+  const int h0 = __builtin_bit_cast(int, f.Hv[lane]), h1 = __builtin_bit_cast(int, f.Hv[lane + 64]);
+  const int r0 = __builtin_bit_cast(int, f.Rv[lane]), r1 = __builtin_bit_cast(int, f.Rv[lane + 64]);
+  const float a11 = f.A[0], a12 = f.A[1], a13 = f.A[2], a21 = f.A[3], a22 = f.A[4], a23 = f.A[5], a31 = f.A[6], a32 = f.A[7], a33 = f.A[8];
+  float c[NP], s[NP], cf[NP], sf[NP], pp[NP], p[NP], d[NP], bbr[NP], bbt[NP], bbf[NP], x[NP], y[NP], am[NP];
+  int k[NP];
+  bool pole[NP];
+  int kmax = 0;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const float xgeo = a11 * xg[i] + a21 * yg[i] + a31 * zg[i];
+    const float ygeo = a12 * xg[i] + a22 * yg[i] + a32 * zg[i];
+    const float zgeo = a13 * xg[i] + a23 * yg[i] + a33 * zg[i];
+    const float rho2 = xgeo * xgeo + ygeo * ygeo;
+    const float r = sqrtf(rho2 + zgeo * zgeo);
+    c[i] = zgeo / r;
+    const float rho = sqrtf(rho2);
+    s[i] = rho / r;
+    pole[i] = s[i] < 1.e-5f;
+    cf[i] = pole[i] ? 1.f : xgeo / rho;
+    sf[i] = pole[i] ? 0.f : ygeo / rho;
+    pp[i] = 1.f / r;
+    const int irp3 = (int)(r + 2.f);
+    int nm = 3 + 30 / (irp3 < 1 ? 1 : irp3);
+    if (nm > 13) nm = 13;
+    k[i] = nm + 1;
+    kmax = k[i] > kmax ? k[i] : kmax;
+    p[i] = 1.f;
+    d[i] = bbr[i] = bbt[i] = bbf[i] = x[i] = 0.f;
+    y[i] = 1.f;
+    am[i] = pp[i] * pp[i]; // A(m) = pp^(m+1)
+  }
   for (int off = 32; off > 0; off >>= 1) {
     const int o = __shfl_xor(kmax, off, 64);
     kmax = o > kmax ? o : kmax;
   }
   kmax = __builtin_amdgcn_readfirstlane(kmax);
-  float p = 1.f, d = 0.f, bbr = 0.f, bbt = 0.f, bbf = 0.f, x = 0.f, y = 1.f;
-  float am = pp * pp; // A(m) = pp^(m+1)
   for (int m = 1; m <= kmax; ++m) {
-    if (m <= k) {
-      if (m > 1) {
-        const float w = x;
-        x = w * cf + y * sf;
-        y = y * cf - w * sf;
+    float q[NP], z[NP], bi[NP], p2[NP], d2[NP], an[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      if (m <= k[i] && m > 1) {
+        const float w = x[i];
+        x[i] = w * cf[i] + y[i] * sf[i];
+        y[i] = y[i] * cf[i] - w * sf[i];
       }
-      float q = p, z = d, bi = 0.f, p2 = 0.f, d2 = 0.f, an = am;
-      for (int n = m; n <= kmax; ++n) {
-        const int mn = n * (n - 1) / 2 + m - 1;
-        const float e = f.G[mn], hh = f.H[mn], xk = f.REC[mn];
-        if (n <= k) {
-          const float w = e * y + hh * x;
-          bbr = bbr + (an * (float)n) * w * q;
-          bbt = bbt - an * w * z;
-          if (m != 1) bi = bi + an * (e * x - hh * y) * (pole ? z : q);
-          const float dp = c * z - s * q - xk * d2;
-          const float pm = c * q - xk * p2;
-          d2 = z;
-          p2 = q;
-          z = dp;
-          q = pm;
-          an = an * pp;
+      q[i] = p[i];
+      z[i] = d[i];
+      bi[i] = p2[i] = d2[i] = 0.f;
+      an[i] = am[i];
+    }
+    const int base = igrf_off(m) - m;
+    for (int n = m; n <= kmax; ++n) {
+      const int t = base + n, j = t & 63; // wave-uniform
+      const float e = __builtin_bit_cast(float, t >= 64 ? __builtin_amdgcn_readlane(g1, j) : __builtin_amdgcn_readlane(g0, j));
+      const float hh = __builtin_bit_cast(float, t >= 64 ? __builtin_amdgcn_readlane(h1, j) : __builtin_amdgcn_readlane(h0, j));
+      const float xk = __builtin_bit_cast(float, t >= 64 ? __builtin_amdgcn_readlane(r1, j) : __builtin_amdgcn_readlane(r0, j));
+      const float fn = (float)n;
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        if (n <= k[i]) { // implies m <= k
+          const float w = e * y[i] + hh * x[i];
+          bbr[i] = bbr[i] + (an[i] * fn) * w * q[i];
+          bbt[i] = bbt[i] - an[i] * w * z[i];
+          if (m != 1) bi[i] = bi[i] + an[i] * (e * x[i] - hh * y[i]) * (pole[i] ? z[i] : q[i]);
+          const float dp = c[i] * z[i] - s[i] * q[i] - xk * d2[i];
+          const float pm = c[i] * q[i] - xk * p2[i];
+          d2[i] = z[i];
+          p2[i] = q[i];
+          z[i] = dp;
+          q[i] = pm;
+          an[i] = an[i] * pp[i];
         }
       }
-      d = s * d + c * p;
-      p = s * p;
-      if (m != 1) bbf = bbf + bi * (float)(m - 1);
-      am = am * pp;
+    }
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      if (m <= k[i]) {
+        d[i] = s[i] * d[i] + c[i] * p[i];
+        p[i] = s[i] * p[i];
+        if (m != 1) bbf[i] = bbf[i] + bi[i] * (float)(m - 1);
+        am[i] = am[i] * pp[i];
+      }
     }
   }
-  float bf;
-  if (pole) bf = c < 0.f ? -bbf : bbf;
-  else bf = bbf / s;
-  const float he = bbr * s + bbt * c;
-  const float hxgeo = he * cf - bf * sf, hygeo = he * sf + bf * cf, hzgeo = bbr * c - bbt * s;
-  hx = f.A[0] * hxgeo + f.A[1] * hygeo + f.A[2] * hzgeo;
-  hy = f.A[3] * hxgeo + f.A[4] * hygeo + f.A[5] * hzgeo;
-  hz = f.A[6] * hxgeo + f.A[7] * hygeo + f.A[8] * hzgeo;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    float bf;
+    if (pole[i]) bf = c[i] < 0.f ? -bbf[i] : bbf[i];
+    else bf = bbf[i] / s[i];
+    const float he = bbr[i] * s[i] + bbt[i] * c[i];
+    const float hxgeo = he * cf[i] - bf * sf[i], hygeo = he * sf[i] + bf * cf[i], hzgeo = bbr[i] * c[i] - bbt[i] * s[i];
+    hx[i] = a11 * hxgeo + a12 * hygeo + a13 * hzgeo;
+    hy[i] = a21 * hxgeo + a22 * hygeo + a23 * hzgeo;
+    hz[i] = a31 * hxgeo + a32 * hygeo + a33 * hzgeo;
+  }
+}
+
+// x_gsm = SM_TO_GSM_d(x); IGRF_GSM(real(x_gsm/R_E)) in nT; (B + 0)*1e-9; GSM_TO_SM_d   (interp_..adapter.f95:186,236-267)
+template <int NP>
+__device__ __forceinline__ void bfield_igrf(const FieldConst &f, const double (&pt)[NP][3], double (&B)[NP][3]) {
+  float xg[NP], yg[NP], zg[NP], hx[NP], hy[NP], hz[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    xg[i] = (float)((pt[i][0] * f.cm - pt[i][2] * f.sm) / R_E);
+    yg[i] = (float)(pt[i][1] / R_E);
+    zg[i] = (float)((pt[i][2] * f.cm + pt[i][0] * f.sm) / R_E);
+  }
+  igrf_core<NP>(f, xg, yg, zg, hx, hy, hz);
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const double gx = (double)(hx[i] + 0.0f) * 1.0e-9, gy = (double)(hy[i] + 0.0f) * 1.0e-9, gz = (double)(hz[i] + 0.0f) * 1.0e-9;
+    B[i][0] = gx * f.cm + gz * f.sm;
+    B[i][1] = gy;
+    B[i][2] = gz * f.cm - gx * f.sm;
+  }
+}
+__device__ __noinline__ void bfield_igrf1(const FieldConst &f, double x, double y, double z, double B[3]) {
+  const double pt[1][3] = {{x, y, z}};
+  double b[1][3];
+  bfield_igrf<1>(f, pt, b);
+  B[0] = b[0][0];
+  B[1] = b[0][1];
+  B[2] = b[0][2];
 }
 
 // ---------------------------------------------------------------------------------------------
 // Dipole B in SM coordinates, then the adapters' GSM round trip through float32 nT
 // (bmodel_dipole.f95:20-48; interp_dens_model_adapter.f95:243-267 and its twins; SURVEY A-8).
 // Trig-free form: B = Bo R_E^3 / r^5 * (-3xz, -3yz, x^2 + y^2 - 2 z^2).
-__device__ __forceinline__ void bfield(const FieldConst &f, double x, double y, double z, double B[3]) {
-  if (f.use_igrf) { // wave-uniform
-    // x_gsm = SM_TO_GSM_d(x); IGRF_GSM(real(x_gsm/R_E)) in nT; (B + 0)*1e-9; GSM_TO_SM_d
-    const double xg = x * f.cm - z * f.sm, zg = z * f.cm + x * f.sm;
-    float hx, hy, hz;
-    igrf_gsm(f, (float)(xg / R_E), (float)(y / R_E), (float)(zg / R_E), hx, hy, hz);
-    const double gx = (double)(hx + 0.0f) * 1.0e-9, gy = (double)(hy + 0.0f) * 1.0e-9, gz = (double)(hz + 0.0f) * 1.0e-9;
-    B[0] = gx * f.cm + gz * f.sm;
-    B[1] = gy;
-    B[2] = gz * f.cm - gx * f.sm;
+template <class CM>
+__device__ __forceinline__ void bfield(const CM &cm, double x, double y, double z, double B[3]) {
+  const FieldConst &f = cm.fld;
+  if (field_is_igrf(cm)) { // wave-uniform, or a compile-time constant
+    bfield_igrf1(f, x, y, z, B);
     return;
   }
   double rho2 = x * x + y * y;

@@ -51,12 +51,25 @@ __device__ __forceinline__ void stencil_points(const double x[3], double del, do
 // raytracer_evalrhs (raytracer.f95:282-314) given the densities at the 7 stencil points: 7 dipole-field
 // evaluations, 3 + 6 Stix evaluations, 14 dispersion-function evaluations.  Also returns dF/dk and dF/dw
 // at the centre (the group-velocity terms of raytracer.f95:916-919 are the same numbers).
-template <int NP>
-__device__ __forceinline__ void rhs_from_plasma(const Common &cm, const double x[3], const double k[3], double w,
+template <int NP, class CM>
+__device__ __forceinline__ void rhs_from_plasma(const CM &cm, const double x[3], const double k[3], double w,
                                                 const double d[3], const double (&p)[NP][3],
                                                 const double (&Ns)[NP][4], double rhs[6], double dk[3], double &dw,
                                                 double B[3]) {
-  bfield(cm.fld, x[0], x[1], x[2], B);
+  // use_igrf (wave-uniform): the seven fields are synthesised together (srt_device.hpp igrf_core); dipole: one by one
+  const bool igrf = field_is_igrf(cm);
+  double Ball[7][3];
+  if (igrf) {
+    double p7[7][3];
+#pragma unroll
+    for (int i = 0; i < 7; ++i)
+      for (int c = 0; c < 3; ++c) p7[i][c] = p[i][c];
+    bfield_igrf<7>(cm.fld, p7, Ball);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) B[c] = Ball[0][c];
+  } else {
+    bfield(cm, x[0], x[1], x[2], B);
+  }
   double B2 = B[0] * B[0] + B[1] * B[1] + B[2] * B[2];
   double Bmag = sqrt(B2);
   Stix st0 = stix_parameters(cm.sp, w, Ns[0], Bmag);
@@ -72,7 +85,12 @@ __device__ __forceinline__ void rhs_from_plasma(const Common &cm, const double x
     for (int s = 0; s < 2; ++s) {
       const int i = 1 + 2 * c + s;
       double Bp[3];
-      bfield(cm.fld, p[i][0], p[i][1], p[i][2], Bp);
+      if (igrf) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) Bp[q] = Ball[i][q];
+      } else {
+        bfield(cm, p[i][0], p[i][1], p[i][2], Bp);
+      }
       double Bp2 = Bp[0] * Bp[0] + Bp[1] * Bp[1] + Bp[2] * Bp[2];
       Stix st = stix_parameters(cm.sp, w, Ns[i], sqrt(Bp2));
       Fpm[s] = dispersion_F(st, n, Bp, Bp2);
@@ -87,8 +105,8 @@ __device__ __forceinline__ void rhs_from_plasma(const Common &cm, const double x
   }
 }
 
-template <class M>
-__device__ __forceinline__ void evalrhs(const M &m, const Common &cm, const double x[6], double w, double del,
+template <class M, class CM>
+__device__ __forceinline__ void evalrhs(const M &m, const CM &cm, const double x[6], double w, double del,
                                         double rhs[6], double *lds, bool need = true) {
   double p[7][3], d[3], Ns[7][4], dk[3], dw, B[3];
   stencil_points<7>(x, del, p, d);
@@ -116,8 +134,8 @@ __constant__ Tableau TAB_RK4 = {{{0, 0, 0, 0, 0}, {0.5, 0, 0, 0, 0}, {0, 0.5, 0,
 
 // r1 = evalrhs at x when the caller already has it (first stage; it does not depend on dt, so it is carried
 // from the previous accepted step and across rejected attempts), else nullptr.
-template <class M>
-__device__ __forceinline__ void rk_stages(const M &m, const Common &cm, const Tableau &tab, const double x[6],
+template <class M, class CM>
+__device__ __forceinline__ void rk_stages(const M &m, const CM &cm, const Tableau &tab, const double x[6],
                                           double w, double del, double dt, double (&ks)[6][6], double *lds,
                                           const double *r1 = nullptr, bool need = true) {
 #pragma unroll
@@ -198,10 +216,11 @@ __device__ __forceinline__ void store_row(double *row, double t, const double x[
 
 // =============================================================================================
 // raytracer_run for a whole launch set (raytracer.f95:609-995 x the driver loop :1144-1232).
-template <class M, bool FIXED, bool USE_LDS>
+template <class M, bool FIXED, bool USE_LDS, bool IGRF = false>
 __global__ __launch_bounds__(64) void trace_kernel(const M *__restrict__ mp, const Common *__restrict__ cp, TraceArgs a) {
   const M &m = *mp;
-  const Common &cm = *cp;
+  typedef typename std::conditional<IGRF, CommonIgrf, CommonDipole>::type CM;
+  const CM &cm = *static_cast<const CM *>(cp);
   __shared__ __attribute__((aligned(16))) double tile[USE_LDS ? TILE_DOUBLES : 2];
   double *lds = USE_LDS ? tile : nullptr;
   const TraceParams &P = a.p;
@@ -308,7 +327,7 @@ __global__ __launch_bounds__(64) void trace_kernel(const M *__restrict__ mp, con
     PointState ps2;
 #pragma unroll
     for (int s = 0; s < 4; ++s) ps2.Ns[s] = NP_[0][s];
-    bfield(cm.fld, est2[0], est2[1], est2[2], ps2.B);
+    bfield(cm, est2[0], est2[1], est2[2], ps2.B);
     ps2.B2 = ps2.B[0] * ps2.B[0] + ps2.B[1] * ps2.B[1] + ps2.B[2] * ps2.B[2];
     ps2.Bmag = sqrt(ps2.B2);
     if (!FIXED) {
@@ -328,7 +347,7 @@ __global__ __launch_bounds__(64) void trace_kernel(const M *__restrict__ mp, con
         PointState ps1;
 #pragma unroll
         for (int s = 0; s < 4; ++s) ps1.Ns[s] = NP_[NPOST - 1][s];
-        bfield(cm.fld, est1[0], est1[1], est1[2], ps1.B);
+        bfield(cm, est1[0], est1[1], est1[2], ps1.B);
         ps1.B2 = ps1.B[0] * ps1.B[0] + ps1.B[1] * ps1.B[1] + ps1.B[2] * ps1.B[2];
         ps1.Bmag = sqrt(ps1.B2);
         double d1[3], d2[3];
@@ -497,7 +516,7 @@ __global__ __launch_bounds__(64) void params_kernel(const M *__restrict__ mp, co
   double Ns[1][4];
   m.template density<1>(p, Ns, tile);
   double B[3];
-  bfield(cm.fld, p[0][0], p[0][1], p[0][2], B);
+  bfield(cm, p[0][0], p[0][1], p[0][2], B);
   if (i < n) {
     double *o = out + 19 * i;
     for (int s = 0; s < 4; ++s) {
@@ -525,7 +544,7 @@ __global__ __launch_bounds__(64) void dispersion_kernel(const M *__restrict__ mp
   double Ns[1][4];
   m.template density<1>(p, Ns, tile);
   double B[3];
-  bfield(cm.fld, p[0][0], p[0][1], p[0][2], B);
+  bfield(cm, p[0][0], p[0][1], p[0][2], B);
   double B2 = B[0] * B[0] + B[1] * B[1] + B[2] * B[2];
   Stix st = stix_parameters(cm.sp, ww, Ns[0], sqrt(B2));
   double cw = cm.C / ww;
@@ -564,7 +583,7 @@ __global__ __launch_bounds__(64) void gradients_kernel(const M *__restrict__ mp,
   m.template density<1>(p, Ns, tile);
   PointState ps;
   for (int s = 0; s < 4; ++s) ps.Ns[s] = Ns[0][s];
-  bfield(cm.fld, st[0], st[1], st[2], ps.B);
+  bfield(cm, st[0], st[1], st[2], ps.B);
   ps.B2 = ps.B[0] * ps.B[0] + ps.B[1] * ps.B[1] + ps.B[2] * ps.B[2];
   ps.Bmag = sqrt(ps.B2);
   double dk[3], dw;
