@@ -14,6 +14,12 @@ module srt_bindc
      real(c_double) :: dt0, dtmax, tmax, maxerr, minalt, del
      integer(c_int32_t) :: maxsteps, root, fixedstep, outputper, first_attempt_policy, refill_threshold, ray_order
   end type srt_params
+  ! srt_damping_params of include/srt.h (the MATLAB post-processor matlab/damping/, SURVEY 8f-3)
+  type, bind(C) :: srt_damping_params
+     integer(c_int32_t) :: dist, mode, nres
+     integer(c_int32_t) :: m(8)
+     real(c_double) :: Ne_h, kT, tol
+  end type srt_damping_params
 
   interface
      integer(c_int) function srt_init(device) bind(C, name="srt_init")
@@ -49,6 +55,29 @@ module srt_bindc
        import :: c_ptr
        type(c_ptr), value :: model
      end subroutine srt_model_destroy
+     ! --use_igrf / --use_tsyganenko of the driver (interp_dens_model_adapter.f95:214-267 and twins); coeff_file may be
+     ! c_null_char-terminated empty string's address replaced by c_null_ptr semantics: pass c_null_char for the default
+     integer(c_int) function srt_model_set_field(model, use_igrf, use_tsyganenko, igrf_coeff_file) &
+          bind(C, name="srt_model_set_field")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: model
+       integer(c_int), value :: use_igrf, use_tsyganenko
+       type(c_ptr), value :: igrf_coeff_file   ! c_null_ptr = the table shipped beside the library
+     end function srt_model_set_field
+     ! hot-plasma damping along the kept rows: rate(slots,nrays), magnitude(slots,nrays), flag(slots,nrays)
+     integer(c_int) function srt_damping(dp, nspec, qs, ms, slots, outputper, nrays, rows, nrows, w0, rate, magnitude, flag) &
+          bind(C, name="srt_damping")
+       import :: c_int, c_int32_t, c_int64_t, c_double, srt_damping_params
+       type(srt_damping_params), intent(in) :: dp
+       integer(c_int), value :: nspec
+       real(c_double), intent(in) :: qs(*), ms(*)
+       integer(c_int32_t), value :: slots, outputper
+       integer(c_int64_t), value :: nrays
+       real(c_double), intent(in) :: rows(*), w0(*)
+       integer(c_int32_t), intent(in) :: nrows(*)
+       real(c_double) :: rate(*), magnitude(*)
+       integer(c_int32_t) :: flag(*)
+     end function srt_damping
      integer(c_int) function srt_model_nspec(model) bind(C, name="srt_model_nspec")
        import :: c_int, c_ptr
        type(c_ptr), value :: model
