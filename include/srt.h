@@ -211,10 +211,6 @@ int srt_damping_device(const srt_damping_params *dp, int nspec, const double *qs
                        int32_t outputper, int64_t nrays, const double *d_rows, const int32_t *d_nrows,
                        const double *d_w0, double *d_rate, double *d_magnitude, int32_t *d_flag, void *stream);
 
-/* self-test hook: the library's own elementary functions for the scattered model's weights (csrc/srt_fastmath.hpp)
- * evaluated on the device: fn 0 = exp(t) for t <= 709, 1 = ln(x) for x > 0, 2 = cos(x) for 0 <= x <= pi */
-int srt_selftest_math(int fn, int64_t n, const double *in, double *out);
-
 /* ---- file formats of the boundary ---- */
 /* ray input file: 7 list-directed reals per line (raytracer_driver.f95:1146); returns count, fills
  * malloc'd arrays the caller frees with srt_free */

@@ -109,7 +109,6 @@ def lib():
                                                      C.POINTER(vp)]
     L.srt_build_samples.argtypes = [vp, C.POINTER(SamplerParams), C.c_int64, dp, C.POINTER(C.c_int64), C.POINTER(dp),
                                     C.POINTER(C.c_int64)]
-    L.srt_selftest_math.argtypes = [C.c_int, C.c_int64, dp, dp]
     L.srt_damping.argtypes = [C.POINTER(DampingParams), C.c_int, dp, dp, C.c_int32, C.c_int32, C.c_int64, dp, ip, dp, dp,
                               dp, ip]
     L.srt_damping_device.argtypes = [C.POINTER(DampingParams), C.c_int, dp, dp, C.c_int32, C.c_int32, C.c_int64, vp, vp,
@@ -342,14 +341,6 @@ def damping(species, outputper, rows, nrows, w0, **kw):
     _check(lib().srt_damping(C.byref(p), qs.size, _dp(qs), _dp(ms), slots, outputper, nrays, _dp(rows),
                              nrows.ctypes.data_as(ip), _dp(w0), _dp(rate), _dp(mag), flag.ctypes.data_as(ip)))
     return rate, mag, flag
-
-
-def selftest_math(fn, x):
-    """exp_fast / log_pos / cos_0pi of csrc/srt_fastmath.hpp on the device (fn = 0, 1, 2)."""
-    x = _f64(x).reshape(-1)
-    out = np.empty_like(x)
-    _check(lib().srt_selftest_math(int(fn), x.size, _dp(x), _dp(out)))
-    return out
 
 
 def is_right_handed(rows):

@@ -1287,26 +1287,6 @@ extern "C" int srt_damping(const srt_damping_params *dp, int nspec, const double
 }
 
 
-// ---- self-test hook for srt_fastmath.hpp (tests/test_gpu_fastmath.py): fn 0 exp_fast, 1 log_pos, 2 cos_0pi ----
-__global__ void fastmath_kernel(int fn, long long n, const double *in, double *out) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const double x = in[i];
-  out[i] = fn == 0 ? exp_fast(x) : fn == 1 ? log_pos(x) : cos_0pi(x);
-}
-extern "C" int srt_selftest_math(int fn, int64_t n, const double *in, double *out) {
-  if (fn < 0 || fn > 2 || n < 0 || !in || !out) return srt_set_error(SRT_EINVAL, "bad argument");
-  if (n == 0) return SRT_OK;
-  int rc = ensure_init();
-  if (rc) return rc;
-  DevBuf din, dout;
-  if ((rc = upload(din, in, n))) return rc;
-  if (dout.alloc(n)) return srt_set_error(SRT_ENOMEM, "hipMalloc failed");
-  hipLaunchKernelGGL(fastmath_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, fn, (long long)n, (const double *)din.p, dout.p);
-  HIP_OK(hipMemcpy(out, dout.p, n * sizeof(double), hipMemcpyDeviceToHost));
-  return SRT_OK;
-}
-
 // AoS [n][3] -> SoA [3][n]
 __global__ void aos_to_soa3(const double *in, double *out, long long n) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;

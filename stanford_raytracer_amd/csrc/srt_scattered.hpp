@@ -12,7 +12,6 @@
 //   solve A y = e_1 (Cholesky, dposv 'U'), ln N_s(x) = y . b_s           [== dot(aa, vals) with aa = (E y) * dinv]
 #pragma once
 #include "srt_device.hpp"
-#include "srt_fastmath.hpp"
 
 namespace srt {
 
@@ -27,17 +26,16 @@ struct ScatteredModel {
 
   __device__ __forceinline__ double etainv(double r, double hin) const {
     const double eps = 5.0e-16;
-    double win = 0.5 + 0.5 * cos_0pi(r * 2.0 * PI / radius / 2.0);
+    double win = 0.5 + 0.5 * cos(r * 2.0 * PI / radius / 2.0);
     if (exact == 1) {
       double q = r / hin;
       return ((1.0 + eps) / (exp(q * q) - 1.0 + eps)) * win;
     }
     double h = hin / 4.0;
     // ((r + radius*eps)/h)**1.1 as x * exp(0.1 ln x): x > 0 always; within ~2 ulp of pow() (the exponent 0.1 ln x is
-    // small, so the logarithm's rounding is damped).  cos on [0, pi], ln of a positive number and exp without special
-    // cases come from srt_fastmath.hpp (~1 ulp, a quarter of the general library's instructions).
+    // small, so the logarithm's rounding is damped), at a third of its instruction count
     double x = (r + radius * eps) / h;
-    return exp_fast(-(x * exp_fast(0.1 * log_pos(x)))) * win;
+    return exp(-(x * exp(0.1 * log(x)))) * win;
   }
 
   // visit every sample within `radius` of x (strictly inside, kdtree_mod.f95:171)
@@ -102,7 +100,7 @@ struct ScatteredModel {
     int count = 0;
     double sw = 0.0, swv = 0.0;
     for_neighbours(x, [&](const double *q, double, double, double, double r) {
-      double cw = 0.5 + 0.5 * cos_0pi(r * 2.0 * PI / radius / 2.0);
+      double cw = 0.5 + 0.5 * cos(r * 2.0 * PI / radius / 2.0);
       sw += cw;
       swv += cw * q[7];
       ++count;
@@ -460,7 +458,7 @@ struct ScatteredModel {
             double d0 = q0 - pg[gg][0], d1 = q1 - pg[gg][1], d2 = q2 - pg[gg][2];
             double ss = d0 * d0 + d1 * d1 + d2 * d2;
             if (((livemask >> (8 * gg)) & 1ull) && ss < r2) {
-              double cw = 0.5 + 0.5 * cos_0pi(sqrt(ss) * 2.0 * PI / radius / 2.0);
+              double cw = 0.5 + 0.5 * cos(sqrt(ss) * 2.0 * PI / radius / 2.0);
               s8[gg] += cw;
               v8[gg] += cw * q7;
               c8[gg] += 1;
@@ -483,7 +481,7 @@ struct ScatteredModel {
           const double *q = pts + (size_t)i * 8;
           double d0 = q[0] - p[0], d1 = q[1] - p[1], d2 = q[2] - p[2];
           double r = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
-          double cw = 0.5 + 0.5 * cos_0pi(r * 2.0 * PI / radius / 2.0);
+          double cw = 0.5 + 0.5 * cos(r * 2.0 * PI / radius / 2.0);
           sw += cw;
           swv += cw * q[7];
           ++count;
