@@ -90,6 +90,15 @@ static void shell_point(uint64_t seed, uint64_t stream, uint64_t i, uint64_t try
 static int inside(const double p[3], const double lo[3], const double hi[3]) {
   return p[0] > lo[0] && p[0] < hi[0] && p[1] > lo[1] && p[1] < hi[1] && p[2] > lo[2] && p[2] < hi[2];
 }
+/* Deliberate divergence shared with the device builder: a sample whose ln N is not finite (log(0) inside the Earth for
+ * the in-scope models) is left out of the box statistics -- in the reference one such sample turns the variance of every
+ * enclosing box into NaN, and `NaN > alpha` being false ends all refinement from the root down. */
+static int counted(const pool_t *P, const double *r, const double rlo[3], const double rhi[3]) {
+  if (!inside(r, rlo, rhi)) return 0;
+  for (int s = 0; s < P->nspec; ++s)
+    if (!isfinite(r[3 + s])) return 0;
+  return 1;
+}
 
 /* one side of randomsampling_mod.f95:76-134 (lower) / :136-193 (upper) */
 static void recursivesampler(pool_t *P, const double limit_min[3], const double limit_max[3], double alpha, int depth,
@@ -106,7 +115,7 @@ static void one_side(pool_t *P, const double lmin[3], const double lmax[3], doub
     rhi[c] = center[c] + upper[c];
   }
   long cnt = 0;
-  for (long i = 0; i < P->n; ++i) cnt += inside(P->rec + (size_t)i * 7, rlo, rhi);
+  for (long i = 0; i < P->n; ++i) cnt += counted(P, P->rec + (size_t)i * 7, rlo, rhi);
   int j = 0; /* draw counter of this half */
   if (cnt <= 2) {
     for (int i = 0; i < numincrease; ++i, ++j) {
@@ -122,7 +131,7 @@ static void one_side(pool_t *P, const double lmin[3], const double lmax[3], doub
   double sum[4] = {0, 0, 0, 0};
   for (long i = 0; i < P->n; ++i) {
     const double *r = P->rec + (size_t)i * 7;
-    if (!inside(r, rlo, rhi)) continue;
+    if (!counted(P, r, rlo, rhi)) continue;
     cnt++;
     for (int s = 0; s < P->nspec; ++s) sum[s] += r[3 + s];
   }
@@ -133,7 +142,7 @@ static void one_side(pool_t *P, const double lmin[3], const double lmax[3], doub
     double sq = 0.0;
     for (long i = 0; i < P->n; ++i) {
       const double *r = P->rec + (size_t)i * 7;
-      if (!inside(r, rlo, rhi)) continue;
+      if (!counted(P, r, rlo, rhi)) continue;
       sq += (r[3 + s] - mean[s]) * (r[3 + s] - mean[s]);
     }
     var = var + 1.0 / (double)(cnt - 1) * sq;

@@ -216,7 +216,17 @@ __global__ __launch_bounds__(64) void smp_stats_kernel(int nhalf, long long npoo
     else hi = mid;
   }
   const long long end = lo;
-  long long cnt = end - beg;
+  // Samples whose ln N is not finite (a model with zero density inside the Earth gives log(0)) are left out of the
+  // statistics: one of them makes every enclosing box's variance NaN and `NaN > alpha` is false, which silently ends
+  // all refinement from the root down (deliberate divergence; they stay in the output for the caller).
+  auto finite4 = [&](const double *r) {
+    bool ok = true;
+    for (int s = 0; s < nspec; ++s) ok = ok && isfinite(r[s]);
+    return ok;
+  };
+  long long mycnt = 0;
+  for (long long q = beg + lane; q < end; q += WAVE) mycnt += finite4(rec + (size_t)sidx[q] * SMP_REC + 3) ? 1 : 0;
+  long long cnt = (long long)smp_wave_sum((double)mycnt);
   const bool a = cnt <= 2; // "If we have too few points, then add some"
   // The candidates lie inside the half by construction, but kdtree_search_rect's strict test is applied to them
   // like to any other sample (a draw of exactly 0 would sit on the face).
@@ -235,7 +245,7 @@ __global__ __launch_bounds__(64) void smp_stats_kernel(int nhalf, long long npoo
   bool cand_in = false;
   if (a && lane < ninc) {
     const double p[3] = {cd[lane * SMP_REC], cd[lane * SMP_REC + 1], cd[lane * SMP_REC + 2]};
-    cand_in = smp_inside(p, rlo, rhi);
+    cand_in = smp_inside(p, rlo, rhi) && finite4(cd + lane * SMP_REC + 3);
   }
   const int ncand = __popcll(__ballot(cand_in));
   cnt += ncand;
@@ -243,6 +253,7 @@ __global__ __launch_bounds__(64) void smp_stats_kernel(int nhalf, long long npoo
   double sum[4] = {0, 0, 0, 0};
   for (long long q = beg + lane; q < end; q += WAVE) {
     const double *r = rec + (size_t)sidx[q] * SMP_REC + 3;
+    if (!finite4(r)) continue;
     for (int s = 0; s < nspec; ++s) sum[s] += r[s];
   }
   if (cand_in)
@@ -252,6 +263,7 @@ __global__ __launch_bounds__(64) void smp_stats_kernel(int nhalf, long long npoo
   double sq[4] = {0, 0, 0, 0};
   for (long long q = beg + lane; q < end; q += WAVE) {
     const double *r = rec + (size_t)sidx[q] * SMP_REC + 3;
+    if (!finite4(r)) continue;
     for (int s = 0; s < nspec; ++s) sq[s] += (r[s] - mean[s]) * (r[s] - mean[s]);
   }
   if (cand_in)
