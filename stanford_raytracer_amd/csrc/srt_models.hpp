@@ -38,7 +38,8 @@ struct NgoModel {
   double hl2n[10], hl2s[10], hu2n[10], hu2s[10];
   int num, kducts, kinit;
 
-  __device__ inline void dens_point(double x, double y, double z, double Ns[4]) const {
+  // noinline: ONE compiled body, so that a point gets the same arithmetic whichever path (and lane) evaluates it
+  __device__ __noinline__ void dens_point(double x, double y, double z, double Ns[4]) const {
     double rho2 = x * x + y * y;
     double r2 = rho2 + z * z;
     double r = sqrt(r2);
@@ -164,9 +165,45 @@ struct NgoModel {
 #pragma unroll
     for (int i = 0; i < NP; ++i) dens_point(p[i][0], p[i][1], p[i][2], Ns[i]);
   }
+  // Stencil of one right-hand side: centre, centre +- d_a e_a, optionally one free point.  All 64 lanes call together.
+  // Tail mode: a launch ends with a few long rays (config[1]: 27 of 100 k rays run to maxsteps while the mean ray
+  // stops after 29 steps), one per wave, each doing its 7-8 density evaluations one after the other while 56+ lanes
+  // idle.  When at most 8 lanes of the wave need a stencil, the k-th needy lane's points are spread over lanes
+  // 8k .. 8k+7 -- one dens_point per lane instead of eight in a row -- and the results shuffled back.  Same function,
+  // same arguments, another lane: bit-identical results.
   template <int NE>
   __device__ __forceinline__ void density_stencil(const double c[3], const double d[3], const double *extra,
-                                                  double (&Ns)[7 + NE][4], double *, bool = true) const {
+                                                  double (&Ns)[7 + NE][4], double *, bool need = true) const {
+    const unsigned long long needy = __ballot(need);
+    const int nneedy = __popcll(needy);
+    if (nneedy >= 1 && nneedy <= 8) { // wave-uniform
+      const int lane = (int)__lane_id(), slot = lane >> 3, pt = lane & 7;
+      unsigned long long mask = needy;
+      for (int k = 0; k < slot && mask; ++k) mask &= mask - 1; // drop the `slot` lowest needy lanes
+      const int owner = (slot < nneedy) ? __builtin_ctzll(mask) : lane;
+      double q[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const double oc = __shfl(c[a], owner), od = __shfl(d[a], owner), oe = NE ? __shfl(extra[a], owner) : 0.0;
+        double v = oc;
+        v = (pt == 1 + 2 * a) ? oc + od : v;
+        v = (pt == 2 + 2 * a) ? oc - od : v;
+        v = (NE && pt == 7) ? oe : v;
+        q[a] = v;
+      }
+      double mine[4];
+      dens_point(q[0], q[1], q[2], mine);
+      // rank of this lane among the needy ones = the slot that served it
+      const int rank = __popcll(needy & ((1ull << lane) - 1ull));
+#pragma unroll
+      for (int i = 0; i < 7 + NE; ++i)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const double v = __shfl(mine[s], 8 * rank + i);
+          if (need) Ns[i][s] = v;
+        }
+      return;
+    }
     dens_point(c[0], c[1], c[2], Ns[0]);
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
