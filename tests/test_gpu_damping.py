@@ -113,3 +113,14 @@ def test_bad_arguments(traced):
         api.damping(g.species(), per, rows, nrows, w0, dist=1, kT=0.0)
     with pytest.raises(api.SrtError):
         api.damping(g.species(), 0, rows, nrows, w0)
+
+
+def test_rays_without_rows_and_empty_batches(traced):
+    """A ray with a single row has nothing to damp (magnitude 1 in slot 0, 0 beyond); an empty batch is a no-op."""
+    g, rows, nrows, w0, per = traced
+    one = nrows.copy()
+    one[:5] = 1
+    k, m, f = api.damping(g.species(), per, rows, one, w0)
+    assert np.all(k[:5] == 0) and np.all(m[:5, 0] == 1.0) and np.all(m[:5, 1:] == 0.0) and np.all(f[:5] == 0)
+    k0, m0, f0 = api.damping(g.species(), per, rows[:0], nrows[:0], w0[:0])
+    assert k0.shape == (0, rows.shape[1])

@@ -109,3 +109,15 @@ def test_bad_requests_are_refused(gpu_models):
     inside = np.array([0.3, 0.4, 0.3, 0.4, 0.3, 0.4]) * wl.R_E       # no point of r >= R_E at all
     with pytest.raises(api.SrtError, match="radial stage"):
         g.build_samples(inside, n_initial_radial=1, seed=1)
+
+
+def test_empty_and_degenerate_requests(gpu_models):
+    """No stage asked for -> empty set; input points only -> returned unchanged; nothing adaptive when nmax = 0."""
+    g = gpu_models["interp"]
+    s, c = g.build_samples(BOUNDS)
+    assert s.shape == (0, 7) and c == [0] * 6
+    pts = np.array([[1.5 * wl.R_E, 0.0, 0.0, 20.0, 18.0, 17.0, 16.0], [0.0, 2.0 * wl.R_E, 0.0, 19.0, 17.0, 16.0, 15.0]])
+    s, c = g.build_samples(BOUNDS, input_points=pts)
+    assert np.array_equal(s, pts) and c == [2, 0, 0, 0, 0, 0]
+    s, c = g.build_samples(BOUNDS, n_zero_altitude=50, seed=2)
+    assert c[4] == len(s) and np.allclose(np.linalg.norm(s[:, :3], axis=1), wl.R_E, rtol=1e-12)
