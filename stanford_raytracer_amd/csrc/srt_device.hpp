@@ -126,6 +126,64 @@ __device__ __forceinline__ void igrf_core(const FieldConst &f, const float (&xg)
     kmax = o > kmax ? o : kmax;
   }
   kmax = __builtin_amdgcn_readfirstlane(kmax);
+  // The points of one stencil lie within 1e-6 of each other: they share the truncation degree unless r + 2 crosses an
+  // integer between them.  Then ONE predicate per lane and trip covers all NP chains (the per-point form below costs
+  // an exec-mask save/restore per point and trip).
+  bool samek = true;
+#pragma unroll
+  for (int i = 1; i < NP; ++i) samek = samek && k[i] == k[0];
+  if (NP > 1 && __all(samek)) {
+    const int kl = k[0];
+    for (int m = 1; m <= kmax; ++m) {
+      float q[NP], z[NP], bi[NP], p2[NP], d2[NP], an[NP];
+      const bool mlive = m <= kl;
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        if (mlive && m > 1) {
+          const float w = x[i];
+          x[i] = w * cf[i] + y[i] * sf[i];
+          y[i] = y[i] * cf[i] - w * sf[i];
+        }
+        q[i] = p[i];
+        z[i] = d[i];
+        bi[i] = p2[i] = d2[i] = 0.f;
+        an[i] = am[i];
+      }
+      const int base = igrf_off(m) - m;
+      for (int n = m; n <= kmax; ++n) {
+        const int t = base + n, j = t & 63; // wave-uniform
+        const float e = __builtin_bit_cast(float, t >= 64 ? __builtin_amdgcn_readlane(g1, j) : __builtin_amdgcn_readlane(g0, j));
+        const float hh = __builtin_bit_cast(float, t >= 64 ? __builtin_amdgcn_readlane(h1, j) : __builtin_amdgcn_readlane(h0, j));
+        const float xk = __builtin_bit_cast(float, t >= 64 ? __builtin_amdgcn_readlane(r1, j) : __builtin_amdgcn_readlane(r0, j));
+        const float fn = (float)n;
+        if (n <= kl) {
+#pragma unroll
+          for (int i = 0; i < NP; ++i) {
+            const float w = e * y[i] + hh * x[i];
+            bbr[i] = bbr[i] + (an[i] * fn) * w * q[i];
+            bbt[i] = bbt[i] - an[i] * w * z[i];
+            if (m != 1) bi[i] = bi[i] + an[i] * (e * x[i] - hh * y[i]) * (pole[i] ? z[i] : q[i]);
+            const float dp = c[i] * z[i] - s[i] * q[i] - xk * d2[i];
+            const float pm = c[i] * q[i] - xk * p2[i];
+            d2[i] = z[i];
+            p2[i] = q[i];
+            z[i] = dp;
+            q[i] = pm;
+            an[i] = an[i] * pp[i];
+          }
+        }
+      }
+      if (mlive) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+          d[i] = s[i] * d[i] + c[i] * p[i];
+          p[i] = s[i] * p[i];
+          if (m != 1) bbf[i] = bbf[i] + bi[i] * (float)(m - 1);
+          am[i] = am[i] * pp[i];
+        }
+      }
+    }
+  } else
   for (int m = 1; m <= kmax; ++m) {
     float q[NP], z[NP], bi[NP], p2[NP], d2[NP], an[NP];
 #pragma unroll
