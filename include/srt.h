@@ -238,6 +238,16 @@ int srt_grid_file_write(const char *path, int binary, int nspec, int nx, int ny,
 int srt_grid_file_convert(const char *in_text_or_binary, const char *out_binary);
 int srt_grid_file_is_binary(const char *path);
 
+/* model-4 sample files: the text format written by gcpm_dens_model_buildgrid_random.f95:196-225 (+ helper
+ * module :37-43) and read by scattered_interp_dens_model_adapter.f95:85-133, and a binary side-format ("SRTPTS01":
+ * 136-byte header {magic, nspec, 0, npts, bounds[6], qs[4], ms[4]} + npts records of 3 + nspec raw doubles).
+ * srt_model_create_scattered_file() accepts either (detected by the magic).  records = [npts][3 + nspec]
+ * "x y z lnN_1 .. lnN_nspec", e.g. the output of srt_build_samples.  Pure host code, needs no GPU. */
+int srt_points_file_write(const char *path, int binary, int nspec, int64_t npts, const double bounds[6],
+                          const double *qs, const double *ms, const double *records);
+int srt_points_file_convert(const char *in_text, const char *out_binary);
+int srt_points_file_is_binary(const char *path);
+
 #ifdef __cplusplus
 }
 #endif

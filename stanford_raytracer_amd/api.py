@@ -118,6 +118,9 @@ def lib():
     L.srt_grid_file_write.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, dp, dp, dp, dp, dp]
     L.srt_grid_file_convert.argtypes = [C.c_char_p, C.c_char_p]
     L.srt_grid_file_is_binary.argtypes = [C.c_char_p]
+    L.srt_points_file_write.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int64, dp, dp, dp, dp]
+    L.srt_points_file_convert.argtypes = [C.c_char_p, C.c_char_p]
+    L.srt_points_file_is_binary.argtypes = [C.c_char_p]
     _lib = L
     return L
 
@@ -420,3 +423,20 @@ def convert_grid_file(src, dst_binary):
 
 def grid_file_is_binary(path):
     return bool(lib().srt_grid_file_is_binary(path.encode()))
+
+
+def write_points_file(path, records, bounds, qs, ms, binary=False):
+    """Model-4 sample file from records[n, 3+nspec] (e.g. Model.build_samples' output): the reference builder's text
+    layout, or the binary side-format."""
+    rec = _f64(records)
+    n, w = rec.shape
+    _check(lib().srt_points_file_write(os.fsencode(path), int(bool(binary)), w - 3, n, _dp(_f64(bounds, (6,))),
+                                       _dp(_f64(qs)), _dp(_f64(ms)), _dp(rec)))
+
+
+def convert_points_file(src_text, dst_binary):
+    _check(lib().srt_points_file_convert(os.fsencode(src_text), os.fsencode(dst_binary)))
+
+
+def points_file_is_binary(path):
+    return bool(lib().srt_points_file_is_binary(os.fsencode(path)))

@@ -6,6 +6,7 @@
 // flags are read as reals and floored (driver:195-196).  Where the reference leaves an unset flag
 // uninitialised we fail with a message instead (documented divergence).
 #include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -59,57 +60,13 @@ static void need(bool ok, const char *name) {
     }                                                                    \
   } while (0)
 
-int main(int argc, char **argv) {
-  g_argc = argc;
-  g_argv = argv;
-  if (argc == 1) {
-    puts("Usage:\n  raytracer --param1=value1 --param2=value2 ...\n"
-         "  --dt0 --dtmax --tmax --root --fixedstep --maxerr --maxsteps --minalt\n"
-         "  --inputraysfile --outputfile --outputper\n"
-         "  --modelnum  (1) Ngo model  (3) interpolated model (gridded)  (4) interpolated model (scattered)\n"
-         "  model 1: --ngo_configfile --yearday --milliseconds_day --use_tsyganenko=0 --use_igrf=0|1\n"
-         "  model 3: --interp_interpfile --yearday --milliseconds_day --use_tsyganenko=0 --use_igrf=0|1\n"
-         "  model 4: model 3 flags + --scattered_interp_window_scale --scattered_interp_order\n"
-         "           --scattered_interp_exact --scattered_interp_local_window_scale\n"
-         "  extra:   --device=N  --first_attempt_policy=0|1  --chunk_rays=N  --ray_order=0|1\n"
-         "  tools:   --grid2bin_in=<text grid> --grid2bin_out=<binary grid>   (convert and exit; --interp_interpfile\n"
-         "           accepts either form)");
-    return 0;
-  }
-  {
-    std::string gin, gout; // model-3 grid: text -> binary side-format (no GPU needed)
-    if (getopt_named("grid2bin_in", gin)) {
-      need(getopt_named("grid2bin_out", gout), "grid2bin_out");
-      CHECK(srt_grid_file_convert(gin.c_str(), gout.c_str()));
-      return 0;
-    }
-  }
-  srt_params p;
-  memset(&p, 0, sizeof p);
-  int modelnum = 0, device = 0, chunk = 0;
-  std::string rays_path, out_path, file;
-  need(get_real("dt0", p.dt0), "dt0");
-  need(get_real("tmax", p.tmax), "tmax");
-  need(get_int("root", p.root), "root");
-  need(get_int("fixedstep", p.fixedstep), "fixedstep");
-  need(get_int("maxsteps", p.maxsteps), "maxsteps");
-  need(get_real("minalt", p.minalt), "minalt");
-  need(getopt_named("inputraysfile", rays_path), "inputraysfile");
-  need(getopt_named("outputfile", out_path), "outputfile");
+// model flags of the driver (raytracer_driver.f95:256-770) -> model handle; del = the driver's FD step for the model
+static int make_model(int device, srt_model **out, double *del) {
+  int modelnum = 0;
+  std::string file;
   need(get_int("modelnum", modelnum), "modelnum");
-  if (p.fixedstep == 0) {
-    need(get_real("dtmax", p.dtmax), "dtmax");
-    need(get_real("maxerr", p.maxerr), "maxerr");
-  } else {
-    get_real("dtmax", p.dtmax);
-    get_real("maxerr", p.maxerr);
-  }
-  p.outputper = 1;
-  get_int("outputper", p.outputper);
-  get_int("device", device);
-  get_int("first_attempt_policy", p.first_attempt_policy);
-  get_int("ray_order", p.ray_order);
-  get_int("chunk_rays", chunk);
+  srt_params p; // only p.del is set here
+  memset(&p, 0, sizeof p);
   int yearday = 0, msec = 0, use_tsy = 0, use_igrf = 0;
   need(get_int("yearday", yearday), "yearday");
   need(get_int("milliseconds_day", msec), "milliseconds_day");
@@ -151,11 +108,137 @@ int main(int argc, char **argv) {
     getopt_named("igrf_coeffs", coeffs); // ours: table of Gauss coefficients (default: shipped beside the library)
     CHECK(srt_model_set_field(m, 1, 0, coeffs.empty() ? nullptr : coeffs.c_str()));
   }
+  *out = m;
+  *del = p.del;
+  return 0;
+}
+
+int main(int argc, char **argv) {
+  g_argc = argc;
+  g_argv = argv;
+  if (argc == 1) {
+    puts("Usage:\n  raytracer --param1=value1 --param2=value2 ...\n"
+         "  --dt0 --dtmax --tmax --root --fixedstep --maxerr --maxsteps --minalt\n"
+         "  --inputraysfile --outputfile --outputper\n"
+         "  --modelnum  (1) Ngo model  (3) interpolated model (gridded)  (4) interpolated model (scattered)\n"
+         "  model 1: --ngo_configfile --yearday --milliseconds_day --use_tsyganenko=0 --use_igrf=0|1\n"
+         "  model 3: --interp_interpfile --yearday --milliseconds_day --use_tsyganenko=0 --use_igrf=0|1\n"
+         "  model 4: model 3 flags + --scattered_interp_window_scale --scattered_interp_order\n"
+         "           --scattered_interp_exact --scattered_interp_local_window_scale\n"
+         "  extra:   --device=N  --first_attempt_policy=0|1  --chunk_rays=N  --ray_order=0|1\n"
+         "  tools:   --grid2bin_in=<text grid> --grid2bin_out=<binary grid>   (convert and exit; --interp_interpfile\n"
+         "           accepts either form);  --pts2bin_in / --pts2bin_out: the same for model-4 sample files\n"
+         "           --buildsamples=1 --filename=<out> --minx .. --maxz --n_initial_uniform ... (the reference's random grid\n"
+         "           builder with the model of --modelnum in place of GCPM; --seed, --binary=1)\n"
+         "           --damping_out=<file>: hot-plasma damping along the kept rows (raynum, row, t, rate, magnitude, flag)");
+    return 0;
+  }
+  {
+    std::string gin, gout; // model-3 grid: text -> binary side-format (no GPU needed)
+    if (getopt_named("grid2bin_in", gin)) {
+      need(getopt_named("grid2bin_out", gout), "grid2bin_out");
+      CHECK(srt_grid_file_convert(gin.c_str(), gout.c_str()));
+      return 0;
+    }
+  }
+  {
+    std::string pin, pout; // model-4 sample file: text -> binary side-format (no GPU needed)
+    if (getopt_named("pts2bin_in", pin)) {
+      need(getopt_named("pts2bin_out", pout), "pts2bin_out");
+      CHECK(srt_points_file_convert(pin.c_str(), pout.c_str()));
+      return 0;
+    }
+  }
+  {
+    // the reference's gcpm_dens_model_buildgrid_random with the model of --modelnum in place of GCPM: same flags
+    // (gcpm_dens_model_buildgrid_random.f95:56-90), --filename = output; ours: --seed, --binary=1
+    std::string fname;
+    if (getopt_named("buildsamples", fname) && fname != "0") {
+      std::string out;
+      need(getopt_named("filename", out), "filename");
+      srt_sampler_params sp;
+      memset(&sp, 0, sizeof sp);
+      const char *bn[6] = {"minx", "maxx", "miny", "maxy", "minz", "maxz"};
+      for (int k = 0; k < 6; ++k) need(get_real(bn[k], sp.bounds[k]), bn[k]);
+      double v = 0;
+      if (get_real("n_zero_altitude", v)) sp.n_zero_altitude = (int64_t)floor(v);
+      if (get_real("n_iri_pad", v)) sp.n_iri_pad = (int64_t)floor(v);
+      if (get_real("n_initial_radial", v)) sp.n_initial_radial = (int64_t)floor(v);
+      if (get_real("n_initial_uniform", v)) sp.n_initial_uniform = (int64_t)floor(v);
+      sp.adaptive_nmax = 100000; // :92
+      if (get_real("adaptive_nmax", v)) sp.adaptive_nmax = (int64_t)floor(v);
+      get_real("initial_tol", sp.initial_tol);
+      get_int("max_recursion", sp.max_recursion);
+      if (get_real("seed", v)) sp.seed = (uint64_t)v;
+      int device = 0, binary = 0;
+      get_int("device", device);
+      get_int("binary", binary);
+      srt_model *m = nullptr;
+      double del = 0.0;
+      int rc = make_model(device, &m, &del);
+      if (rc) return rc;
+      int64_t n = 0, counts[6];
+      double *rec = nullptr;
+      CHECK(srt_build_samples(m, &sp, 0, nullptr, &n, &rec, counts));
+      double qs[SRT_MAXSPEC], ms[SRT_MAXSPEC];
+      srt_model_species(m, qs, ms);
+      CHECK(srt_points_file_write(out.c_str(), binary, srt_model_nspec(m), n, sp.bounds, qs, ms, rec));
+      printf(" %lld samples: %lld radial, %lld uniform, %lld adaptive, %lld zero-altitude, %lld ionosphere\n", (long long)n,
+             (long long)counts[1], (long long)counts[2], (long long)counts[3], (long long)counts[4], (long long)counts[5]);
+      srt_free(rec);
+      srt_model_destroy(m);
+      return 0;
+    }
+  }
+  srt_params p;
+  memset(&p, 0, sizeof p);
+  int device = 0, chunk = 0;
+  std::string rays_path, out_path;
+  need(get_real("dt0", p.dt0), "dt0");
+  need(get_real("tmax", p.tmax), "tmax");
+  need(get_int("root", p.root), "root");
+  need(get_int("fixedstep", p.fixedstep), "fixedstep");
+  need(get_int("maxsteps", p.maxsteps), "maxsteps");
+  need(get_real("minalt", p.minalt), "minalt");
+  need(getopt_named("inputraysfile", rays_path), "inputraysfile");
+  need(getopt_named("outputfile", out_path), "outputfile");
+  if (p.fixedstep == 0) {
+    need(get_real("dtmax", p.dtmax), "dtmax");
+    need(get_real("maxerr", p.maxerr), "maxerr");
+  } else {
+    get_real("dtmax", p.dtmax);
+    get_real("maxerr", p.maxerr);
+  }
+  p.outputper = 1;
+  get_int("outputper", p.outputper);
+  get_int("device", device);
+  get_int("first_attempt_policy", p.first_attempt_policy);
+  get_int("ray_order", p.ray_order);
+  get_int("chunk_rays", chunk);
+  srt_model *m = nullptr;
+  {
+    double del = 0.0;
+    int rc = make_model(device, &m, &del);
+    if (rc) return rc;
+    p.del = del;
+  }
   double *pos0 = nullptr, *dir0 = nullptr, *w0 = nullptr;
   int64_t nrays = srt_read_rays_file(rays_path.c_str(), &pos0, &dir0, &w0);
   if (nrays < 0) {
     fprintf(stderr, "raytracer: %s\n", srt_last_error());
     return 1;
+  }
+  // ours: --damping_out=<file> [--damping_dist=0|1 --damping_mode=0|1 --damping_Ne_h --damping_kT_eV --damping_tol]
+  std::string damp_path;
+  srt_damping_params dpar;
+  memset(&dpar, 0, sizeof dpar);
+  if (getopt_named("damping_out", damp_path)) {
+    get_int("damping_dist", dpar.dist);
+    get_int("damping_mode", dpar.mode);
+    get_real("damping_Ne_h", dpar.Ne_h);
+    double kTeV = 0;
+    if (get_real("damping_kT_eV", kTeV)) dpar.kT = kTeV * 1.60217646e-19;
+    get_real("damping_tol", dpar.tol);
   }
   const int slots = srt_rows_per_ray(&p);
   double qs[SRT_MAXSPEC], ms[SRT_MAXSPEC];
@@ -183,6 +266,26 @@ int main(int argc, char **argv) {
     CHECK(srt_trace_batch(m, &p, n, pos0 + 3 * lo, dir0 + 3 * lo, w0 + lo, rows.data(), nrows.data(), stop.data(), &steps));
     total_steps += steps;
     CHECK(srt_write_ray_file(out_path.c_str(), 1, lo + 1, n, &p, nspec, qs, ms, w0 + lo, rows.data(), nrows.data(), stop.data()));
+    if (!damp_path.empty()) {
+      // the MATLAB post-processor (matlab/damping/test_dampray.m) on the rows just traced: one record per kept row
+      std::vector<double> rate((size_t)n * slots), mag((size_t)n * slots);
+      std::vector<int32_t> flag((size_t)n * slots);
+      CHECK(srt_damping(&dpar, nspec, qs, ms, slots, p.outputper, n, rows.data(), nrows.data(), w0 + lo, rate.data(), mag.data(), flag.data()));
+      FILE *f = fopen(damp_path.c_str(), lo == 0 ? "w" : "a");
+      if (!f) {
+        fprintf(stderr, "raytracer: cannot open %s\n", damp_path.c_str());
+        return 1;
+      }
+      for (int64_t i = 0; i < n; ++i) {
+        const int kept = nrows[i] > 0 ? (nrows[i] - 1) / p.outputper + 1 : 0;
+        for (int r = 0; r < kept && r < slots; ++r) {
+          const size_t idx = (size_t)i * slots + r;
+          fprintf(f, "%10lld%10d%25.15E%25.15E%25.15E%10d\n", (long long)(lo + i + 1), r * p.outputper + 1, rows[idx * SRT_ROW], rate[idx], mag[idx],
+                  (int)flag[idx]);
+        }
+      }
+      fclose(f);
+    }
   }
   printf(" %lld rays, %lld accepted steps\n", (long long)nrays, (long long)total_steps);
   srt_free(pos0);

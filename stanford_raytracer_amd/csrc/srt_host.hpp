@@ -66,6 +66,9 @@ namespace srt_host {
 // model-4 scattered sample file (scattered_interp_dens_model_adapter.f95:85-133) prepared for the device:
 // duplicates dropped (:160-163), nearest-sample distance per sample outside the Earth (:167-203),
 // samples binned into a uniform grid with cell edge = maxnearest*window_scale and sorted by cell.
+bool is_binary_points(const char *path);
+bool write_points_file(const char *path, bool binary, int nspec, int64_t npts, const double bounds[6], const double *qs, const double *ms,
+                       const double *rec, std::string &err);
 struct ScatteredHost {
   int nspec = 0, npts = 0;
   double qs[4] = {0}, ms[4] = {0};

@@ -1,6 +1,7 @@
 // srt_scattered_host.cpp -- host-side preparation of the scattered-sample model (no device code).
 #include <algorithm>
 #include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <numeric>
@@ -46,10 +47,82 @@ void build_grid(const std::vector<double> &xyz, int n, double cell, const double
 }
 } // namespace
 
+// ---- binary side-format of the model-4 sample file: "SRTPTS01", int32 nspec, int32 0, int64 npts,
+// bounds[6], qs[4], ms[4] (136-byte header), then npts records of 3 + nspec little-endian doubles ----
+static const char PTS_MAGIC[8] = {'S', 'R', 'T', 'P', 'T', 'S', '0', '1'};
+struct PtsHeader {
+  char magic[8];
+  int32_t nspec, zero;
+  int64_t npts;
+  double bounds[6], qs[4], ms[4];
+};
+bool is_binary_points(const char *path) {
+  FILE *f = fopen(path, "rb");
+  if (!f) return false;
+  char m[8];
+  const bool ok = fread(m, 1, 8, f) == 8 && memcmp(m, PTS_MAGIC, 8) == 0;
+  fclose(f);
+  return ok;
+}
+static bool read_points_binary(const char *path, PtsHeader &h, std::vector<double> &raw, std::string &err) {
+  FILE *f = fopen(path, "rb");
+  if (!f) { err = "cannot open"; return false; }
+  bool ok = fread(&h, sizeof h, 1, f) == 1 && memcmp(h.magic, PTS_MAGIC, 8) == 0 && h.nspec >= 1 && h.nspec <= 4 && h.npts >= 0;
+  if (ok) {
+    raw.resize((size_t)h.npts * (size_t)(3 + h.nspec));
+    ok = fread(raw.data(), sizeof(double), raw.size(), f) == raw.size();
+  }
+  fclose(f);
+  if (!ok) err = "truncated or malformed binary sample file";
+  return ok;
+}
+bool write_points_file(const char *path, bool binary, int nspec, int64_t npts, const double bounds[6], const double *qs, const double *ms,
+                       const double *rec, std::string &err) {
+  FILE *f = fopen(path, binary ? "wb" : "w");
+  if (!f) { err = "cannot open for writing"; return false; }
+  bool ok = true;
+  if (binary) {
+    PtsHeader h;
+    memset(&h, 0, sizeof h);
+    memcpy(h.magic, PTS_MAGIC, 8);
+    h.nspec = nspec;
+    h.npts = npts;
+    for (int k = 0; k < 6; ++k) h.bounds[k] = bounds[k];
+    for (int k = 0; k < nspec; ++k) { h.qs[k] = qs[k]; h.ms[k] = ms[k]; }
+    ok = fwrite(&h, sizeof h, 1, f) == 1 && fwrite(rec, sizeof(double), (size_t)npts * (3 + nspec), f) == (size_t)npts * (3 + nspec);
+  } else {
+    // gcpm_dens_model_buildgrid_random.f95:196-208 (header) and helpermod :37-43 (one sample per record, es24.15e3)
+    char b[25];
+    fprintf(f, "%10d\n", nspec);
+    for (int k = 0; k < 6; ++k) { format_es24(bounds[k], b); fputs(b, f); }
+    fputc('\n', f);
+    for (int k = 0; k < nspec; ++k) { format_es24(qs[k], b); fputs(b, f); }
+    fputc('\n', f);
+    for (int k = 0; k < nspec; ++k) { format_es24(ms[k], b); fputs(b, f); }
+    fputc('\n', f);
+    std::string line;
+    for (int64_t i = 0; i < npts && ok; ++i) {
+      line.clear();
+      for (int k = 0; k < 3 + nspec; ++k) { format_es24(rec[(size_t)i * (3 + nspec) + k], b); line += b; }
+      line += '\n';
+      ok = fputs(line.c_str(), f) >= 0;
+    }
+  }
+  ok = (fclose(f) == 0) && ok;
+  if (!ok) err = "write failed";
+  return ok;
+}
+
 bool build_scattered(const char *path, double window_scale, ScatteredHost &out, std::string &err) {
   std::vector<double> raw;
   int nspec = 0;
-  {
+  if (is_binary_points(path)) {
+    PtsHeader h;
+    if (!read_points_binary(path, h, raw, err)) return false;
+    nspec = h.nspec;
+    out.nspec = nspec;
+    for (int k = 0; k < nspec; ++k) { out.qs[k] = h.qs[k]; out.ms[k] = h.ms[k]; }
+  } else {
     // fast path: the whole file tokenised by all cores; valid when every record holds exactly what its READ takes
     // (7 header numbers, nspec charges, nspec masses, then 3 + nspec numbers per sample)
     std::vector<double> all;
@@ -195,3 +268,30 @@ bool build_scattered(const char *path, double window_scale, ScatteredHost &out, 
 }
 
 } // namespace srt_host
+
+// ---- C ABI: model-4 sample files (include/srt.h) ----
+#include "../../include/srt.h"
+int srt_set_error(int code, const char *fmt, ...);
+extern "C" int srt_points_file_write(const char *path, int binary, int nspec, int64_t npts, const double bounds[6], const double *qs,
+                                     const double *ms, const double *records) {
+  if (!path || !bounds || !qs || !ms || (npts > 0 && !records) || npts < 0) return srt_set_error(SRT_EINVAL, "bad argument");
+  if (nspec < 1 || nspec > SRT_MAXSPEC) return srt_set_error(SRT_EINVAL, "nspec=%d unsupported", nspec);
+  std::string err;
+  if (!srt_host::write_points_file(path, binary != 0, nspec, npts, bounds, qs, ms, records, err)) return srt_set_error(SRT_EIO, "%s: %s", path, err.c_str());
+  return SRT_OK;
+}
+extern "C" int srt_points_file_is_binary(const char *path) { return path && srt_host::is_binary_points(path) ? 1 : 0; }
+extern "C" int srt_points_file_convert(const char *in, const char *out_binary) {
+  if (!in || !out_binary) return srt_set_error(SRT_EINVAL, "null argument");
+  std::vector<double> all;
+  std::string err;
+  if (srt_host::is_binary_points(in)) return srt_set_error(SRT_EINVAL, "%s is already binary", in);
+  if (!srt_host::read_all_numbers(in, all, err) || all.size() < 7) return srt_set_error(SRT_EIO, "%s: %s", in, err.empty() ? "too short" : err.c_str());
+  const int nspec = (int)all[0];
+  if (nspec < 1 || nspec > 4 || all.size() < (size_t)(7 + 2 * nspec) || (all.size() - 7 - 2 * nspec) % (size_t)(3 + nspec) != 0)
+    return srt_set_error(SRT_EIO, "%s: not a model-4 sample file (or records do not match their READs)", in);
+  const int64_t npts = (int64_t)((all.size() - 7 - 2 * nspec) / (size_t)(3 + nspec));
+  if (!srt_host::write_points_file(out_binary, true, nspec, npts, &all[1], &all[7], &all[7 + nspec], all.data() + 7 + 2 * nspec, err))
+    return srt_set_error(SRT_EIO, "%s: %s", out_binary, err.c_str());
+  return SRT_OK;
+}

@@ -146,3 +146,57 @@ def test_cli_models_3_and_4_write_what_the_library_computes(tmp_path, grid16, po
         assert np.allclose(blk[:, 2:18], want[:, 0:16], rtol=6e-16, atol=0)
         assert np.allclose(blk[:, 28:32], want[:, 16:20], rtol=6e-16, atol=0)
         assert np.allclose(blk[:, 18], w[r], rtol=6e-16)
+
+
+def test_cli_buildsamples_pts2bin_and_damping(tmp_path, cfgfiles):
+    """The tools either side of the path from the command line: the reference's random-grid-builder flags with the
+    model of --modelnum as the source, the binary side-format of the sample file, tracing on the result, and the damping
+    post-pass written next to the .ray file; each checked against the library called directly."""
+    from stanford_raytracer_amd import api
+    exe = os.path.join(BIN, "raytracer")
+    b = np.array([-4.0, 4.0, -4.0, 4.0, -4.0, 4.0]) * wl.R_E
+    model = ["--modelnum=1", "--ngo_configfile=%s" % cfgfiles["ngo"], "--yearday=2010001", "--milliseconds_day=0"]
+    pts, binf = str(tmp_path / "pts.txt"), str(tmp_path / "pts.bin")
+    bflags = ["--%s=%r" % (n, float(v)) for n, v in zip(["minx", "maxx", "miny", "maxy", "minz", "maxz"], b)]
+    r = subprocess.run([exe, "--buildsamples=1", "--filename=%s" % pts, "--n_initial_uniform=3000", "--n_iri_pad=2000",
+                        "--adaptive_nmax=3000", "--initial_tol=1.0", "--max_recursion=14", "--seed=9"] + bflags + model,
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    api.init(0)
+    g = api.Model.ngo(cfgfiles["ngo"])
+    want, counts = g.build_samples(b, n_initial_uniform=3000, n_iri_pad=2000, adaptive_nmax=3000, initial_tol=1.0,
+                                   max_recursion=14, seed=9)
+    got = np.loadtxt(pts, skiprows=4)
+    assert got.shape == want.shape and "%d samples" % len(want) in r.stdout
+    fin = np.isfinite(want)
+    assert np.allclose(got[fin], want[fin], rtol=2e-15, atol=0)
+    # only finite samples make a usable model-4 file
+    keep = np.all(np.isfinite(want), axis=1)
+    qs, ms = g.species()
+    api.write_points_file(pts, want[keep], b, qs, ms)
+    assert subprocess.run([exe, "--pts2bin_in=%s" % pts, "--pts2bin_out=%s" % binf]).returncode == 0
+    x = want[keep][::50, :3] * (1 + 1e-9)
+    a = api.Model.scattered_file(pts, order=1).plasma_params(x)
+    c = api.Model.scattered_file(binf, order=1).plasma_params(x)
+    assert np.array_equal(a, c, equal_nan=True)
+    # trace with the damping post-pass
+    rf, out, dmp = tmp_path / "rays.txt", tmp_path / "o.ray", tmp_path / "o.damp"
+    pos0, dir0, w0 = wl.launch_set(6, 3)
+    wl.write_rays_file(str(rf), pos0, dir0, w0)
+    run = [exe, "--dt0=1e-3", "--dtmax=0.02", "--tmax=0.1", "--root=2", "--fixedstep=0", "--maxerr=5e-4", "--maxsteps=200",
+           "--minalt=%r" % wl.MINALT, "--outputper=4", "--inputraysfile=%s" % rf, "--outputfile=%s" % out,
+           "--damping_out=%s" % dmp] + model
+    assert subprocess.run(run).returncode == 0
+    p = api.make_params(dt0=1e-3, dtmax=0.02, tmax=0.1, maxerr=5e-4, maxsteps=200, minalt=wl.MINALT, outputper=4, del_=1e-4)
+    rows, nrows, stop, _ = g.trace(pos0, dir0, w0, params=p)
+    k, m, f = api.damping(g.species(), 4, rows, nrows, w0)
+    rec = np.loadtxt(str(dmp)).reshape(-1, 6)
+    kept = (nrows - 1) // 4 + 1
+    assert len(rec) == kept.sum()
+    i = 0
+    for ray in range(6):
+        for s in range(kept[ray]):
+            assert rec[i, 0] == ray + 1 and rec[i, 1] == 4 * s + 1 and rec[i, 5] == f[ray, s]
+            assert np.isclose(rec[i, 3], k[ray, s], rtol=1e-13, atol=0, equal_nan=True)
+            assert np.isclose(rec[i, 4], m[ray, s], rtol=1e-13, atol=0, equal_nan=True)
+            i += 1

@@ -164,3 +164,30 @@ def test_grid_binary_side_format_round_trip(tmp_path):
         assert False, "truncated binary grid accepted"
     except api.SrtError as e:
         assert "truncated" in str(e)
+
+
+def test_points_file_text_layout_and_binary_side_format(tmp_path):
+    """Model-4 sample files: the reference builder's record layout (one es24.15e3 field per value,
+    gcpm_dens_model_buildgrid_random.f95:196-208 + helper module :37-43), readable by the oracle's reader; the binary
+    side-format holds the same numbers bit for bit; conversion of a text file gives the same binary."""
+    from oracle import oracle
+    rng = np.random.default_rng(4)
+    n = 300
+    rec = np.concatenate([rng.normal(size=(n, 3)) * 3 * wl.R_E, rng.uniform(10, 25, size=(n, 4))], axis=1)
+    b = np.array([-9.0, 9.0] * 3) * wl.R_E
+    txt, binf, conv = (str(tmp_path / f) for f in ("p.txt", "p.bin", "c.bin"))
+    api.write_points_file(txt, rec, b, wl.QS, wl.MS)
+    api.write_points_file(binf, rec, b, wl.QS, wl.MS, binary=True)
+    lines = open(txt).read().split("\n")
+    assert lines[0] == "%10d" % 4 and len(lines[1]) == 6 * 24 and len(lines[2]) == 4 * 24 and len(lines[4]) == 7 * 24
+    assert lines[4][:24] == "%24s" % ("%.15E" % rec[0, 0]).replace("E+", "E+0").replace("E-", "E-0")
+    vals = np.array([[float(lines[4 + i][24 * k:24 * k + 24]) for k in range(7)] for i in range(n)])
+    assert np.allclose(vals, rec, rtol=2e-15, atol=0)                    # 16 significant digits
+    assert not api.points_file_is_binary(txt) and api.points_file_is_binary(binf)
+    raw = np.fromfile(binf, dtype=np.float64, offset=136)
+    assert np.array_equal(raw.reshape(n, 7), rec)
+    api.convert_points_file(txt, conv)
+    assert np.array_equal(np.fromfile(conv, dtype=np.float64, offset=136).reshape(n, 7), vals)
+    # the oracle's reader (the adapter's READ statements restated) takes the text file
+    o = oracle.Model.scattered_file(txt, order=1)
+    assert o.nspec == 4
