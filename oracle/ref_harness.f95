@@ -87,6 +87,14 @@ program ref_harness
      call do_rh()
      stop
   end if
+  if (trim(mode) == 't04') then
+     call do_t04()
+     stop
+  end if
+  if (trim(mode) == 'ext') then
+     call do_ext()
+     stop
+  end if
 
   if (modelnum == 1) then
      call getopt_named('ngo_configfile', configfile, foundopt)
@@ -237,6 +245,48 @@ contains
     close(71)
     close(72)
   end subroutine do_disp
+
+  ! T04_s itself (tsyganenko/TS05_aka_TS04.for:5): rows "parmod(10) ps x y z" (GSM, R_E) -> bx by bz (REAL, widened)
+  subroutine do_t04()
+    real :: parmod(10), ps, x, y, z, bx, by, bz
+    integer :: status
+    external :: T04_s
+    open(unit=71, file=trim(infile_name), status='old')
+    open(unit=72, file=trim(outfile_name), access='stream', form='unformatted', status='replace')
+    do
+       read(71, *, iostat=status) parmod, ps, x, y, z
+       if (status /= 0) exit
+       call T04_s(0, parmod, ps, x, y, z, bx, by, bz)
+       write(72) real(bx, DP), real(by, DP), real(bz, DP)
+    end do
+    close(71)
+    close(72)
+  end subroutine do_t04
+
+  ! EXTERN (TS05_aka_TS04.for:118) with its module outputs: first record = the 69 model coefficients (T04_s's DATA A,
+  ! supplied by the caller), then rows "pdyn dst byimf bzimf w1..w6 ps x y z" -> 33 doubles: CF, T1, T2, SRC, PRC, R11,
+  ! R12, R21, R22, HIMF, total (3 each)
+  subroutine do_ext()
+    real(kind=DP) :: a(69), pdyn, dst, bximf, byimf, bzimf, w(6), ps, x, y, z, o(33)
+    integer :: status
+    external :: EXTERN
+    open(unit=71, file=trim(infile_name), status='old')
+    open(unit=72, file=trim(outfile_name), access='stream', form='unformatted', status='replace')
+    read(71, *) a
+    bximf = 0.0_DP
+    do
+       read(71, *, iostat=status) pdyn, dst, byimf, bzimf, w, ps, x, y, z
+       if (status /= 0) exit
+       o = 0.0_DP
+       call EXTERN(0, 0, 0, 0, a, 69, pdyn, dst, bximf, byimf, bzimf, w(1), w(2), w(3), w(4), w(5), w(6), ps, x, y, z, &
+            o(1), o(2), o(3), o(4), o(5), o(6), o(7), o(8), o(9), o(10), o(11), o(12), o(13), o(14), o(15), &
+            o(16), o(17), o(18), o(19), o(20), o(21), o(22), o(23), o(24), o(25), o(26), o(27), o(28), o(29), o(30), &
+            o(31), o(32), o(33))
+       write(72) o
+    end do
+    close(71)
+    close(72)
+  end subroutine do_ext
 
   subroutine do_rh()
     real(kind=DP) :: n2, phi, S, D, P, res

@@ -14,7 +14,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 EXE = os.path.join(HERE, "_ref", "ref_harness")
 
-NOUT = {"params": 19, "disp": 10, "grad": 14, "step": 21, "rh": 1}
+NOUT = {"params": 19, "disp": 10, "grad": 14, "step": 21, "rh": 1, "t04": 3, "ext": 33}
 
 
 def available():
