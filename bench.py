@@ -51,6 +51,8 @@ def parse_args():
     ap.add_argument("--points", type=int, default=0, help="override sample count (scattered)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline sample duration (0=skip)")
     ap.add_argument("--use-igrf", type=int, default=0, choices=[0, 1], help="IGRF main field instead of the dipole (driver flag --use_igrf)")
+    ap.add_argument("--use-tsyganenko", type=int, default=0, choices=[0, 1],
+                    help="add the T04_s external field (driver flag --use_tsyganenko; PARMOD = Pdyn 4, Dst -30, By 1, Bz -5, W .1-.3)")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--damping-rays", type=int, default=100_000,
                     help="rays whose kept rows get the damping post-pass after the timed region (N=1 only; 0 = skip)")
@@ -141,9 +143,10 @@ def main():
         setup_s = time.time() - t0
         wname = "%d rays/GPU, ngo_dens_model, dipole B, adaptive RK45" % nrays
 
-    if args.use_igrf:
-        model.set_field(use_igrf=1)
-        wname += ", IGRF main field"
+    if args.use_igrf or args.use_tsyganenko:
+        model.set_field(use_igrf=args.use_igrf, use_tsyganenko=args.use_tsyganenko,
+                        parmod=[4.0, -30.0, 1.0, -5.0, 0.132, 0.303, 0.083, 0.07, 0.211, 0.308])
+        wname += (", IGRF main field" if args.use_igrf else "") + (", T04_s external field" if args.use_tsyganenko else "")
     pos0, dir0, w0 = wl.launch_set(nrays, seed + 1000 * rank)
     p.ray_order = args.ray_order
     slots = api.lib().srt_rows_per_ray(p)
@@ -364,6 +367,8 @@ def cpu_baseline(args, kind, p, wl, pos0, dir0, w0, grid_n):
         with open(cfg, "w") as f:
             f.write(wl.NEWRAY_PLASMAPAUSE)
         om = oracle.Model.ngo(cfg)
+    if args.use_tsyganenko:
+        return {"error": "the CPU port has no T04_s (parity for it is held against goldens of the reference, tests/test_t04.py)"}
     if args.use_igrf:
         om.set_igrf()
     setup = time.time() - t0
@@ -396,6 +401,8 @@ def cpu_reference(args, kind, p, wl, pos0, dir0, w0):
     if not refharness.available() or kind == "scattered":
         return None
     igrf = {"use_igrf": 1} if args.use_igrf else {}
+    if args.use_tsyganenko:
+        return None  # the harness runs T04_s with its own fixed PARMOD
     td = tempfile.mkdtemp()
     if kind == "interp":
         gn = 64

@@ -128,11 +128,16 @@ typedef struct srt_sampler_params {
 int srt_build_samples(srt_model *src, const srt_sampler_params *sp, int64_t n_in, const double *in_pts,
                       int64_t *n_out, double **out, int64_t stage_counts[6]);
 /* Field options of the adapters (driver flags --use_igrf / --use_tsyganenko; interp_dens_model_adapter.f95:214-267
- * and its twins): use_igrf = 1 replaces the dipole by IGRF (geopack2008.for IGRF_GSW_08 after RECALC_08 for the model's
- * yearday / milliseconds_day, fp32 like the Fortran), evaluated on the device at every lookup.  igrf_coeff_file = table
- * of the published Gauss coefficients (NULL: $SRT_IGRF_COEFFS, else the data/igrf_coeffs.txt shipped beside the
- * library).  use_tsyganenko = 1 (T04_s) is not built: SRT_EINVAL. */
+ * and its twins), evaluated on the device at every lookup, in the arithmetic types of the Fortran:
+ *   use_igrf = 1: IGRF main field instead of the dipole (geopack2008.for IGRF_GSW_08 after RECALC_08 for the model's
+ *     yearday / milliseconds_day, REAL);
+ *   use_tsyganenko = 1: the T04_s (Tsyganenko & Sitnov 2005) external field added to it (TS05_aka_TS04.for, REAL*8
+ *     inside, REAL interface), with PARMOD from srt_model_set_tsyganenko_params and geopack's dipole tilt for the date.
+ * igrf_coeff_file = table of the published Gauss coefficients, needed by either option (NULL: $SRT_IGRF_COEFFS, else the
+ * data/igrf_coeffs.txt shipped beside the library). */
 int srt_model_set_field(srt_model *m, int use_igrf, int use_tsyganenko, const char *igrf_coeff_file);
+/* parmod[10] = Pdyn (nPa), Dst (nT), ByIMF, BzIMF (nT), W1 .. W6: the driver's --tsyganenko_* flags */
+int srt_model_set_tsyganenko_params(srt_model *m, const double parmod[10]);
 void srt_model_destroy(srt_model *m);
 int srt_model_kind(const srt_model *m);  /* 1, 3 or 4 */
 int srt_model_nspec(const srt_model *m);

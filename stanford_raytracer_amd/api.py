@@ -80,6 +80,7 @@ def lib():
     L.srt_model_create_scattered_file.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int,
                                                   C.c_double, C.POINTER(vp)]
     L.srt_model_set_field.argtypes = [vp, C.c_int, C.c_int, C.c_char_p]
+    L.srt_model_set_tsyganenko_params.argtypes = [vp, dp]
     L.srt_model_destroy.argtypes = [vp]
     L.srt_model_destroy.restype = None
     L.srt_model_kind.argtypes = [vp]
@@ -241,8 +242,10 @@ class Model:
                                                         _dp(_f64(bounds, (6,))), yearday, msec, C.byref(h)))
         return Model(h)
 
-    def set_field(self, use_igrf=0, use_tsyganenko=0, igrf_coeff_file=None):
-        """--use_igrf / --use_tsyganenko of the driver (Tsyganenko is not built and is refused)."""
+    def set_field(self, use_igrf=0, use_tsyganenko=0, igrf_coeff_file=None, parmod=None):
+        """--use_igrf / --use_tsyganenko of the driver; parmod = Pdyn, Dst, ByIMF, BzIMF, W1..W6 (--tsyganenko_*)."""
+        if parmod is not None:
+            _check(lib().srt_model_set_tsyganenko_params(self.h, _dp(_f64(parmod, (10,)))))
         _check(lib().srt_model_set_field(self.h, int(use_igrf), int(use_tsyganenko),
                                          os.fsencode(igrf_coeff_file) if igrf_coeff_file else None))
         return self

@@ -19,7 +19,7 @@ ARCH = "gfx950"
 
 LIB_SRCS = ["srt_api.hip", "srt_host.cpp", "srt_scattered_host.cpp"]
 CLI_SRCS = ["srt_cli.cpp"]
-HEADERS = ["srt_device.hpp", "srt_models.hpp", "srt_scattered.hpp", "srt_sampler.hpp", "srt_damping.hpp", "srt_kernels.hpp", "srt_host.hpp", "tricubic_matrix.h",
+HEADERS = ["srt_device.hpp", "srt_models.hpp", "srt_scattered.hpp", "srt_sampler.hpp", "srt_damping.hpp", "srt_t04.hpp", "srt_t04_tables.h", "srt_kernels.hpp", "srt_host.hpp", "tricubic_matrix.h",
            os.path.join("..", "..", "include", "srt.h")]
 
 

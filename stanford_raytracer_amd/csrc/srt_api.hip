@@ -167,12 +167,12 @@ extern "C" void srt_model_destroy(srt_model *m) {
 #include <dlfcn.h>
 extern "C" int srt_model_set_field(srt_model *m, int use_igrf, int use_tsyganenko, const char *igrf_coeff_file) {
   if (!m) return srt_set_error(SRT_EINVAL, "null model");
-  if (use_tsyganenko) return srt_set_error(SRT_EINVAL, "use_tsyganenko=1 (T04_s external field) is not built");
+  if (use_tsyganenko != 0 && use_tsyganenko != 1) return srt_set_error(SRT_EINVAL, "use_tsyganenko must be 0 or 1");
   if (use_igrf != 0 && use_igrf != 1) return srt_set_error(SRT_EINVAL, "use_igrf must be 0 or 1");
   int rc = ensure_init();
   if (rc) return rc;
   FieldConst &f = m->cm.fld;
-  if (use_igrf) {
+  if (use_igrf || use_tsyganenko) { // both need geopack's RECALC_08 for the date: coefficients, GEO->GSM matrix, dipole tilt
     std::string path;
     if (igrf_coeff_file && *igrf_coeff_file) path = igrf_coeff_file;
     else if (const char *e = getenv("SRT_IGRF_COEFFS")) path = e;
@@ -186,7 +186,7 @@ extern "C" int srt_model_set_field(srt_model *m, int use_igrf, int use_tsyganenk
     }
     std::string err;
     float G[105], H[105], REC[105];
-    if (!srt_host::igrf_setup(path.c_str(), f.yearday, f.msec, G, H, REC, f.A, err)) return srt_set_error(SRT_EIO, "%s", err.c_str());
+    if (!srt_host::igrf_setup(path.c_str(), f.yearday, f.msec, G, H, REC, f.A, &f.psi, err)) return srt_set_error(SRT_EIO, "%s", err.c_str());
     for (int mm = 1; mm <= 14; ++mm)
       for (int n = mm; n <= 14; ++n) { // geopack's index n(n-1)/2 + m  ->  visiting order
         const int mn = n * (n - 1) / 2 + mm - 1, e = igrf_off(mm) + n - mm;
@@ -196,6 +196,16 @@ extern "C" int srt_model_set_field(srt_model *m, int use_igrf, int use_tsyganenk
       }
   }
   f.use_igrf = use_igrf;
+  f.use_tsy = use_tsyganenko;
+  HIP_OK(hipMemcpy(m->d_common, &m->cm, sizeof(Common), hipMemcpyHostToDevice));
+  return SRT_OK;
+}
+// T04_s's PARMOD (driver flags --tsyganenko_Pdyn, _Dst, _ByIMF, _BzIMF, _W1 .. _W6; raytracer_driver.f95:292-341)
+extern "C" int srt_model_set_tsyganenko_params(srt_model *m, const double parmod[10]) {
+  if (!m || !parmod) return srt_set_error(SRT_EINVAL, "null argument");
+  int rc = ensure_init();
+  if (rc) return rc;
+  for (int i = 0; i < 10; ++i) m->cm.fld.parmod[i] = (float)parmod[i]; // real(parmod)
   HIP_OK(hipMemcpy(m->d_common, &m->cm, sizeof(Common), hipMemcpyHostToDevice));
   return SRT_OK;
 }
@@ -1162,7 +1172,7 @@ extern "C" int srt_trace_batch_device(srt_model *m, const srt_params *p, int64_t
     HIP_OK(hipcub::DeviceRadixSort::SortPairs(sl.d_sorttmp, tb, sl.d_keys[0], sl.d_keys[1], sl.d_ids[0], sl.d_ids[1], (int)nrays, 0, 30, st));
     a.order = sl.d_ids[1];
   }
-  const bool fixed = p->fixedstep != 0, igrf = m->cm.fld.use_igrf != 0;
+  const bool fixed = p->fixedstep != 0, igrf = m->cm.fld.use_igrf != 0 || m->cm.fld.use_tsy != 0;
   // one instantiation per (model, integrator, field option): the dipole kernels carry none of the IGRF code
 #define SRT_LAUNCH_TRACE(MODEL, LDS)                                                                                             \
   do {                                                                                                                           \

@@ -72,10 +72,6 @@ static int make_model(int device, srt_model **out, double *del) {
   need(get_int("milliseconds_day", msec), "milliseconds_day");
   get_int("use_tsyganenko", use_tsy);
   get_int("use_igrf", use_igrf);
-  if (use_tsy != 0) {
-    fprintf(stderr, "raytracer: --use_tsyganenko=1 (T04_s external field) is outside the accelerated path\n");
-    return 2;
-  }
   CHECK(srt_init(device));
   srt_model *m = nullptr;
   // FD step for dF/dx: delSP for the single-precision models, delDP otherwise (driver:251-252, :1158-1176)
@@ -103,10 +99,17 @@ static int make_model(int device, srt_model **out, double *del) {
     fprintf(stderr, "raytracer: --modelnum=%d is not on the accelerated path (1, 3, 4 are)\n", modelnum);
     return 2;
   }
-  if (use_igrf != 0) {
+  if (use_igrf != 0 || use_tsy != 0) {
     std::string coeffs;
     getopt_named("igrf_coeffs", coeffs); // ours: table of Gauss coefficients (default: shipped beside the library)
-    CHECK(srt_model_set_field(m, 1, 0, coeffs.empty() ? nullptr : coeffs.c_str()));
+    if (use_tsy != 0) { // raytracer_driver.f95:292-341
+      const char *names[10] = {"tsyganenko_Pdyn", "tsyganenko_Dst", "tsyganenko_ByIMF", "tsyganenko_BzIMF", "tsyganenko_W1",
+                               "tsyganenko_W2",   "tsyganenko_W3",  "tsyganenko_W4",    "tsyganenko_W5",    "tsyganenko_W6"};
+      double parmod[10];
+      for (int k = 0; k < 10; ++k) need(get_real(names[k], parmod[k]), names[k]);
+      CHECK(srt_model_set_tsyganenko_params(m, parmod));
+    }
+    CHECK(srt_model_set_field(m, use_igrf != 0, use_tsy != 0, coeffs.empty() ? nullptr : coeffs.c_str()));
   }
   *out = m;
   *del = p.del;
@@ -121,8 +124,8 @@ int main(int argc, char **argv) {
          "  --dt0 --dtmax --tmax --root --fixedstep --maxerr --maxsteps --minalt\n"
          "  --inputraysfile --outputfile --outputper\n"
          "  --modelnum  (1) Ngo model  (3) interpolated model (gridded)  (4) interpolated model (scattered)\n"
-         "  model 1: --ngo_configfile --yearday --milliseconds_day --use_tsyganenko=0 --use_igrf=0|1\n"
-         "  model 3: --interp_interpfile --yearday --milliseconds_day --use_tsyganenko=0 --use_igrf=0|1\n"
+         "  model 1: --ngo_configfile --yearday --milliseconds_day --use_tsyganenko=0|1 --use_igrf=0|1 --tsyganenko_Pdyn .. _W6\n"
+         "  model 3: --interp_interpfile --yearday --milliseconds_day --use_tsyganenko=0|1 --use_igrf=0|1\n"
          "  model 4: model 3 flags + --scattered_interp_window_scale --scattered_interp_order\n"
          "           --scattered_interp_exact --scattered_interp_local_window_scale\n"
          "  extra:   --device=N  --first_attempt_policy=0|1  --chunk_rays=N  --ray_order=0|1\n"

@@ -10,6 +10,7 @@
 #include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "srt_t04.hpp"
 
 namespace srt {
 
@@ -35,11 +36,15 @@ struct FieldConst {
   double cm, sm; // cos(mu), sin(mu), mu = dipole tilt for the run's itime
   // use_igrf = 1 (interp_dens_model_adapter.f95:236-241): Schmidt-normalised Gauss coefficients for the run's date,
   // recursion constants and the GEO->GSM matrix, as RECALC_08 leaves them (host: srt_host::igrf_setup)
-  int use_igrf, yearday, msec, pad_;
+  int use_igrf, yearday, msec, use_tsy;
   // g, h, rec per (m, n) term in the ORDER THE SYNTHESIS VISITS THEM (m = 1..14 outer, n = m..14 inner): entry
   // (m, n) sits at igrf_off(m) + n - m.  Padded to 128: lane l of a wave keeps entries l and l + 64 in registers.
   float Gv[128], Hv[128], Rv[128];
   float A[9];
+  // use_tsyganenko = 1 (interp_dens_model_adapter.f95:223-258): T04_s(iopt, real(parmod), real(psi), real(x_gsm/R_E));
+  // parmod = Pdyn, Dst, ByIMF, BzIMF, W1..W6 (driver flags --tsyganenko_*), psi = the adapters' COMMON /GEOPACK1/ PSI,
+  // which aliases geopack's ST0 (see srt_host::igrf_setup)
+  float parmod[10], psi;
 };
 __host__ __device__ inline int igrf_off(int m) { return (m - 1) * 15 - (m - 1) * m / 2; }
 
@@ -48,8 +53,9 @@ struct Common {
   FieldConst fld;
   double C; // speed of light as constants.f95:7 computes it
 };
-// The same constants with the field option fixed at compile time: the trace kernel is instantiated once per option, so
-// that the dipole kernel carries none of the IGRF synthesis' registers or code (sharing one kernel cost it 11 %).
+// The same constants with the field option fixed at compile time: the trace kernel is instantiated once for the plain
+// dipole and once for everything else (IGRF main field and / or T04_s external field, chosen at run time inside), so
+// that the dipole kernel carries none of their registers or code (sharing one kernel cost it 11 %).
 // Plain `Common` means "look at fld.use_igrf at run time" (the layered kernels).
 struct CommonDipole : Common {};
 struct CommonIgrf : Common {};
@@ -57,7 +63,7 @@ template <class CM>
 __device__ __forceinline__ bool field_is_igrf(const CM &cm) {
   if constexpr (std::is_same<CM, CommonDipole>::value) return false;
   else if constexpr (std::is_same<CM, CommonIgrf>::value) return true;
-  else return cm.fld.use_igrf != 0;
+  else return cm.fld.use_igrf != 0 || cm.fld.use_tsy != 0;
 }
 
 // a/b for operands well inside the exponent range (every division of the hot path: frequencies, densities,
@@ -245,7 +251,14 @@ __device__ __forceinline__ void igrf_core(const FieldConst &f, const float (&xg)
   }
 }
 
-// x_gsm = SM_TO_GSM_d(x); IGRF_GSM(real(x_gsm/R_E)) in nT; (B + 0)*1e-9; GSM_TO_SM_d   (interp_..adapter.f95:186,236-267)
+// T04_s on the device: one compiled body (srt_t04.hpp is ~1 000 lines of formulae; it must not be inlined per call site)
+__device__ __noinline__ void t04_device(const FieldConst &f, float xg, float yg, float zg, float &tx, float &ty, float &tz) {
+  t04::t04_s(f.parmod, f.psi, xg, yg, zg, tx, ty, tz);
+}
+
+// The adapters' field tail in full (interp_dens_model_adapter.f95:186,214-267): x_gsm = SM_TO_GSM_d(x); base field in
+// GSM nT as REAL -- IGRF_GSM(real(x_gsm/R_E)), or the dipole rotated to GSM; plus T04_s(real(parmod), real(psi),
+// real(x_gsm/R_E)) when use_tsyganenko; (base + tsy)*1e-9; GSM_TO_SM_d.
 template <int NP>
 __device__ __forceinline__ void bfield_igrf(const FieldConst &f, const double (&pt)[NP][3], double (&B)[NP][3]) {
   float xg[NP], yg[NP], zg[NP], hx[NP], hy[NP], hz[NP];
@@ -255,10 +268,30 @@ __device__ __forceinline__ void bfield_igrf(const FieldConst &f, const double (&
     yg[i] = (float)(pt[i][1] / R_E);
     zg[i] = (float)((pt[i][2] * f.cm + pt[i][0] * f.sm) / R_E);
   }
-  igrf_core<NP>(f, xg, yg, zg, hx, hy, hz);
+  if (f.use_igrf) { // wave-uniform
+    igrf_core<NP>(f, xg, yg, zg, hx, hy, hz);
+  } else {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) { // the dipole, as in bfield() below
+      const double x = pt[i][0], y = pt[i][1], z = pt[i][2];
+      const double rho2 = x * x + y * y, r2 = rho2 + z * z, r = sqrt(r2);
+      const double k = fdiv(f.bo_re3, r2 * r2 * r);
+      const double bx = -3.0 * k * x * z, by = -3.0 * k * y * z, bz = k * (rho2 - 2.0 * z * z);
+      hx[i] = (float)(1.0e9 * (bx * f.cm - bz * f.sm));
+      hy[i] = (float)(1.0e9 * by);
+      hz[i] = (float)(1.0e9 * (bz * f.cm + bx * f.sm));
+    }
+  }
+  float tx[NP], ty[NP], tz[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) tx[i] = ty[i] = tz[i] = 0.0f;
+  if (f.use_tsy) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) t04_device(f, xg[i], yg[i], zg[i], tx[i], ty[i], tz[i]);
+  }
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
-    const double gx = (double)(hx[i] + 0.0f) * 1.0e-9, gy = (double)(hy[i] + 0.0f) * 1.0e-9, gz = (double)(hz[i] + 0.0f) * 1.0e-9;
+    const double gx = (double)(hx[i] + tx[i]) * 1.0e-9, gy = (double)(hy[i] + ty[i]) * 1.0e-9, gz = (double)(hz[i] + tz[i]) * 1.0e-9;
     B[i][0] = gx * f.cm + gz * f.sm;
     B[i][1] = gy;
     B[i][2] = gz * f.cm - gx * f.sm;

@@ -84,7 +84,7 @@ SunAngles sun_angles(int iyear, int iday, int ihour, int min, int isec) {
 } // namespace
 
 bool igrf_setup(const char *coeff_file, int yearday, int msec, float G[105], float H[105], float REC[105], float A[9],
-                std::string &err) {
+                float *psi, std::string &err) {
   // table: "g|h mn v1965 v1970 ... v2020 sv"
   static const int NEP = 12;
   std::vector<float> tg(13 * 105, 0.f), th(13 * 105, 0.f);
@@ -185,6 +185,14 @@ bool igrf_setup(const char *coeff_file, int yearday, int msec, float G[105], flo
   A[6] = z1 * cgst + z2 * sgst;
   A[7] = -z1 * sgst + z2 * cgst;
   A[8] = z3;
+  if (psi) {
+    // What the adapters pass to T04_s as the tilt angle: they declare `real(kind=SP) :: PSI; COMMON /GEOPACK1/ PSI`
+    // (interp_dens_model_adapter.f95:45-46), i.e. PSI is the FIRST word of geopack's block -- and that word is ST0, the
+    // sine of the dipole axis' colatitude (geopack2008.for:569), not RECALC_08's PSI (16th word).  The reference
+    // therefore runs T04_s with PS = ST0 (~0.17 in 2010) whatever the date and hour; parity means doing the same.
+    (void)(dip1 * x1 + dip2 * x2 + dip3 * x3); // RECALC_08's SPS, whose arcsine the adapters never see
+    *psi = st0;
+  }
   return true;
 }
 

@@ -12,7 +12,7 @@ double dipole_tilt(int yearday, int msec);
 // matrix (geopack2008.for RECALC_08 + SUN_08 with V_sw = (-400,0,0), i.e. tsy_recalc of geopack0508_adapter.for:21-30),
 // default REAL arithmetic like the Fortran.  coeff_file = table of IAGA coefficients (data/igrf_coeffs.txt).
 bool igrf_setup(const char *coeff_file, int yearday, int msec, float G[105], float H[105], float REC[105], float A[9],
-                std::string &err);
+                float *psi, std::string &err); // psi: what the adapters hand to T04_s as PS (first word of COMMON /GEOPACK1/ = ST0)
 
 // newray.in card file (ngo_dens_model.f95:45-118; field names per matlab/unused/parse_newray_cards.m)
 struct NgoConfig {

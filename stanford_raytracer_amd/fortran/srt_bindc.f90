@@ -64,6 +64,11 @@ module srt_bindc
        integer(c_int), value :: use_igrf, use_tsyganenko
        type(c_ptr), value :: igrf_coeff_file   ! c_null_ptr = the table shipped beside the library
      end function srt_model_set_field
+     integer(c_int) function srt_model_set_tsyganenko_params(model, parmod) bind(C, name="srt_model_set_tsyganenko_params")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: model
+       real(c_double), intent(in) :: parmod(10)   ! Pdyn, Dst, ByIMF, BzIMF, W1..W6
+     end function srt_model_set_tsyganenko_params
      ! hot-plasma damping along the kept rows: rate(slots,nrays), magnitude(slots,nrays), flag(slots,nrays)
      integer(c_int) function srt_damping(dp, nspec, qs, ms, slots, outputper, nrays, rows, nrows, w0, rate, magnitude, flag) &
           bind(C, name="srt_damping")

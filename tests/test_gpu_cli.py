@@ -65,7 +65,7 @@ def test_cli_rejects_out_of_scope_requests(tmp_path, cfgfiles):
     base = [os.path.join(BIN, "raytracer"), "--dt0=1e-3", "--tmax=0.01", "--root=2", "--fixedstep=1", "--maxsteps=10",
             "--minalt=6.4712e6", "--inputraysfile=%s" % rf, "--outputfile=%s" % (tmp_path / "o.ray"), "--yearday=2010001",
             "--milliseconds_day=0", "--ngo_configfile=%s" % cfgfiles["ngo"]]
-    assert subprocess.run(base + ["--modelnum=1", "--use_tsyganenko=1"]).returncode == 2
+    assert subprocess.run(base + ["--modelnum=1", "--use_tsyganenko=1"]).returncode == 2     # its --tsyganenko_* flags are missing
     assert subprocess.run(base + ["--modelnum=2"]).returncode == 2
     assert subprocess.run(base + ["--modelnum=1"]).returncode == 0
 
@@ -200,3 +200,25 @@ def test_cli_buildsamples_pts2bin_and_damping(tmp_path, cfgfiles):
             assert np.isclose(rec[i, 3], k[ray, s], rtol=1e-13, atol=0, equal_nan=True)
             assert np.isclose(rec[i, 4], m[ray, s], rtol=1e-13, atol=0, equal_nan=True)
             i += 1
+
+
+def test_cli_use_tsyganenko(tmp_path, cfgfiles):
+    """--use_tsyganenko=1 with the driver's --tsyganenko_* flags: row 0 carries dipole + T04_s."""
+    from stanford_raytracer_amd import api
+    rf = tmp_path / "rays.txt"
+    rf.write_text("1.5e7 2e6 1e6 1 0 0 1e4\n")
+    out = tmp_path / "o.ray"
+    parmod = [4.0, -30.0, 1.0, -5.0, 0.132, 0.303, 0.083, 0.07, 0.211, 0.308]
+    names = ["Pdyn", "Dst", "ByIMF", "BzIMF", "W1", "W2", "W3", "W4", "W5", "W6"]
+    run = [os.path.join(BIN, "raytracer"), "--dt0=1e-3", "--tmax=0.01", "--root=2", "--fixedstep=1", "--maxsteps=10",
+           "--minalt=6.4712e6", "--inputraysfile=%s" % rf, "--outputfile=%s" % out, "--yearday=2010001",
+           "--milliseconds_day=0", "--ngo_configfile=%s" % cfgfiles["ngo"], "--modelnum=1", "--use_tsyganenko=1"]
+    run += ["--tsyganenko_%s=%r" % (n, v) for n, v in zip(names, parmod)]
+    assert subprocess.run(run).returncode == 0
+    row0 = [float(v) for v in out.read_text().splitlines()[0].split()]
+    api.init(0)
+    x = [[1.5e7, 2e6, 1e6]]
+    want = api.Model.ngo(cfgfiles["ngo"]).set_field(use_tsyganenko=1, parmod=parmod).plasma_params(x)[0, 16:19]
+    dip = api.Model.ngo(cfgfiles["ngo"]).plasma_params(x)[0, 16:19]
+    got = np.array(row0[15:18])
+    assert np.allclose(got, want, rtol=1e-14, atol=0) and np.abs(got - dip).max() > 1e-9

@@ -70,8 +70,6 @@ def test_gpu_igrf_field_matches_reference_goldens(gold, cfgfiles, grid16):
             dip = m.plasma_params(x)[:, 16:19]
             assert np.abs(dip - want).max() > 0       # and back to the dipole
     with pytest.raises(api.SrtError):
-        api.Model.ngo(cfgfiles["ngo"]).set_field(use_tsyganenko=1)
-    with pytest.raises(api.SrtError):
         api.Model.ngo(cfgfiles["ngo"]).set_field(use_igrf=1, igrf_coeff_file="/nonexistent/table.txt")
 
 
