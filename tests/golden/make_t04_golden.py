@@ -71,6 +71,19 @@ def main():
         ref = refharness.run_mode("params", x, {"kind": 1, "file": cfg, "use_igrf": igrf, "use_tsyganenko": 1, "yearday": yd, "msec": ms})
         store["B_" + tag] = ref[:, 16:19]
         store["date_" + tag] = np.array([yd, ms, igrf])
+    # G4: fixed-step Ngo trajectories in dipole + T04 (the harness's PARMOD), first date
+    pos0, dir0, w0 = wl.appendix_b_rays(8)
+    rays = np.concatenate([pos0, dir0, w0[:, None]], axis=1)
+    kw = dict(dt0=1e-3, dtmax=0.1, maxerr=5e-4, maxsteps=40, minalt=wl.MINALT, root=2, tmax=0.03, fixedstep=1)
+    kw["del"] = 1e-4
+    out, _ = refharness.run_rays({"kind": 1, "file": cfg, "use_tsyganenko": 1, "yearday": 2010001, "msec": 0}, rays, **kw)
+    T = max(len(o["rows"]) for o in out)
+    rr = np.zeros((len(out), T, 20))
+    for i, o in enumerate(out):
+        r = o["rows"]
+        rr[i, :len(r)] = np.concatenate([r[:, :16], r[:, 24:28]], axis=1)
+    store.update(run_pos0=pos0, run_dir0=dir0, run_w0=w0, run_rows=rr, run_nrows=np.array([len(o["rows"]) for o in out]),
+                 run_stop=np.array([o["stopcond"] for o in out]))
     store["provenance"] = np.array("oracle/_ref/ref_harness (flang -O3): TS05_aka_TS04.for, geopack2008.for, ngo adapter")
     np.savez_compressed(os.path.join(HERE, "t04_golden.npz"), **store)
     print("wrote t04_golden.npz", {k: getattr(v, "shape", None) for k, v in store.items()})

@@ -88,6 +88,26 @@ def test_gpu_field_tail_with_t04(gold, cfgfiles, grid16):
 
 
 @pytest.mark.gpu
+def test_gpu_t04_trajectories_against_the_reference(gold, cfgfiles):
+    """Fixed-step Ngo rays in dipole + T04 against the reference's own rows (raytracer_run with use_tsyganenko=1)."""
+    from stanford_raytracer_amd import api
+    api.init(0)
+    m = api.Model.ngo(cfgfiles["ngo"]).set_field(use_tsyganenko=1, parmod=gold["parmod"])
+    p = api.make_params(dt0=1e-3, dtmax=0.1, maxerr=5e-4, maxsteps=40, minalt=wl.MINALT, tmax=0.03, fixedstep=1, del_=1e-4)
+    rows, nrows, stop, _ = m.trace(gold["run_pos0"], gold["run_dir0"], gold["run_w0"], params=p)
+    assert np.array_equal(nrows, gold["run_nrows"]) and np.array_equal(stop, gold["run_stop"])
+    ref = gold["run_rows"]
+    for r in range(ref.shape[0]):
+        T = nrows[r]
+        pos_err = np.linalg.norm(rows[r, :T, 1:4] - ref[r, :T, 1:4], axis=1) / np.linalg.norm(ref[r, :T, 1:4], axis=1)
+        B_err = np.linalg.norm(rows[r, :T, 13:16] - ref[r, :T, 13:16], axis=1) / np.linalg.norm(ref[r, :T, 13:16], axis=1)
+        # row 0: the field itself (fp32 tail); then the drift of a trajectory whose dF/dx sees an fp32 staircase in B
+        # (tests/test_igrf.py::test_gpu_igrf_trajectories has the argument)
+        assert B_err[0] <= 3e-6 and pos_err[1] <= 1e-8
+        assert pos_err.max() <= 5e-3 and B_err.max() <= 5e-3
+
+
+@pytest.mark.gpu
 def test_gpu_trace_with_t04_runs_and_differs_from_dipole(cfgfiles):
     """Rays traced in dipole + T04 finish with sane stop codes; near the Earth the path barely moves (the external
     field is < 1 % of the main field there), and it is not identical."""
