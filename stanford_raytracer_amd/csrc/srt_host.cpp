@@ -190,7 +190,6 @@ bool igrf_setup(const char *coeff_file, int yearday, int msec, float G[105], flo
     // (interp_dens_model_adapter.f95:45-46), i.e. PSI is the FIRST word of geopack's block -- and that word is ST0, the
     // sine of the dipole axis' colatitude (geopack2008.for:569), not RECALC_08's PSI (16th word).  The reference
     // therefore runs T04_s with PS = ST0 (~0.17 in 2010) whatever the date and hour; parity means doing the same.
-    (void)(dip1 * x1 + dip2 * x2 + dip3 * x3); // RECALC_08's SPS, whose arcsine the adapters never see
     *psi = st0;
   }
   return true;

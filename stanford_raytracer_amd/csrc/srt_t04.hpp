@@ -325,32 +325,35 @@ T04_HD static inline Components external_field(const double *A, double PDYN, dou
 // box-harmonic shielding field shared by BIRK_SHL (:1532-1667) and RC_SHIELD (:2376-2512): two sums ("perpendicular"
 // and "parallel" symmetry), 3 x 3 harmonics each, every coefficient split into 4 parts (1, X_SC, f(tilt), f(tilt) X_SC)
 T04_HD static inline V3 shield_86(const double *A, double PS, double X_SC, double X, double Y, double Z, double FAC_SC) {
+  // (the Fortran evaluates the harmonics of BOTH sums inside each of the two M loops and uses half of them; only the
+  // needed ones are evaluated here -- same values, same order of summation)
   const double CPS = cos(PS), SPS = sin(PS), S3PS = 2.0 * CPS;
   const double PST1 = PS * A[84], PST2 = PS * A[85];
   const double ST1 = sin(PST1), CT1 = cos(PST1), ST2 = sin(PST2), CT2 = cos(PST2);
   const double X1 = X * CT1 - Z * ST1, Z1 = X * ST1 + Z * CT1, X2 = X * CT2 - Z * ST2, Z2 = X * ST2 + Z * CT2;
   int L = 0;
   V3 Gv = {0.0, 0.0, 0.0};
-  for (int M = 1; M <= 2; ++M)
+  for (int M = 1; M <= 2; ++M) {
+    const double XM = M == 1 ? X1 : X2, ZM = M == 1 ? Z1 : Z2, CT = M == 1 ? CT1 : CT2, ST = M == 1 ? ST1 : ST2;
+    const double tilt = M == 1 ? CPS : S3PS;
     for (int I = 0; I < 3; ++I) {
-      const double P = A[72 + I], Q = A[78 + I];
-      const double CYPI = cos(Y / P), CYQI = cos(Y / Q), SYPI = sin(Y / P), SYQI = sin(Y / Q);
+      const double P = M == 1 ? A[72 + I] : A[78 + I]; // P (perpendicular sum) or Q (parallel sum)
+      const double CY = cos(Y / P), SY = sin(Y / P);
       for (int K = 0; K < 3; ++K) {
-        const double R = A[75 + K], S = A[81 + K];
-        const double SZRK = sin(Z1 / R), CZSK = cos(Z2 / S), CZRK = cos(Z1 / R), SZSK = sin(Z2 / S);
-        const double SQPR = sqrt(1.0 / (P * P) + 1.0 / (R * R)), SQQS = sqrt(1.0 / (Q * Q) + 1.0 / (S * S));
-        const double EPR = exp(X1 * SQPR), EQS = exp(X2 * SQQS);
+        const double R = M == 1 ? A[75 + K] : A[81 + K]; // R or S
+        const double SZ = sin(ZM / R), CZ = cos(ZM / R);
+        const double SQ = sqrt(1.0 / (P * P) + 1.0 / (R * R));
+        const double E = exp(XM * SQ);
         double FX, FY, FZ;
         if (M == 1) {
-          FX = -SQPR * EPR * CYPI * SZRK * FAC_SC;
-          FY = EPR * SYPI * SZRK / P * FAC_SC;
-          FZ = -EPR * CYPI * CZRK / R * FAC_SC;
+          FX = -SQ * E * CY * SZ * FAC_SC;
+          FY = E * SY * SZ / P * FAC_SC;
+          FZ = -E * CY * CZ / R * FAC_SC;
         } else {
-          FX = -SPS * SQQS * EQS * CYQI * CZSK * FAC_SC;
-          FY = SPS / Q * EQS * SYQI * CZSK * FAC_SC;
-          FZ = SPS / S * EQS * CYQI * SZSK * FAC_SC;
+          FX = -SPS * SQ * E * CY * CZ * FAC_SC;
+          FY = SPS / P * E * SY * CZ * FAC_SC;
+          FZ = SPS / R * E * CY * SZ * FAC_SC;
         }
-        const double tilt = M == 1 ? CPS : S3PS;
         for (int N = 1; N <= 2; ++N)
           for (int NN = 1; NN <= 2; ++NN) {
             double HX = FX, HY = FY, HZ = FZ;
@@ -364,8 +367,7 @@ T04_HD static inline V3 shield_86(const double *A, double PS, double X_SC, doubl
               HY = HY * X_SC;
               HZ = HZ * X_SC;
             }
-            const double HXR = M == 1 ? HX * CT1 + HZ * ST1 : HX * CT2 + HZ * ST2;
-            const double HZR = M == 1 ? -HX * ST1 + HZ * CT1 : -HX * ST2 + HZ * CT2;
+            const double HXR = HX * CT + HZ * ST, HZR = -HX * ST + HZ * CT;
             Gv.x += HXR * A[L];
             Gv.y += HY * A[L];
             Gv.z += HZR * A[L];
@@ -373,6 +375,7 @@ T04_HD static inline V3 shield_86(const double *A, double PS, double X_SC, doubl
           }
       }
     }
+  }
   return Gv;
 }
 
