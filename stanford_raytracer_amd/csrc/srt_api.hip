@@ -76,6 +76,7 @@ struct srt_model {
   InterpModel interp{};
   ScatteredModel scat{};
   double *d_pts = nullptr;
+  double *d_xyz = nullptr; // scattered model: the sample positions once more, SoA [3][npts] (the candidate scans read only these)
   int *d_cells = nullptr;
   double *d_coef = nullptr;
   void *d_model = nullptr;   // device copy of ngo / interp (kernels read it through scalar loads)
@@ -92,6 +93,9 @@ struct srt_model {
     int *d_ids[2] = {nullptr, nullptr};
     void *d_sorttmp = nullptr;
     size_t sort_cap = 0, sorttmp_bytes = 0;
+    // scattered model (grow-only): staging records of coop_stencil, REC_CAP * REC doubles per one-wave block
+    double *d_stage = nullptr;
+    long long stage_blocks = 0;
   };
   static constexpr int NSLOT = 4;
   LaunchSlot slot[NSLOT];
@@ -149,6 +153,7 @@ extern "C" void srt_model_destroy(srt_model *m) {
   if (!m) return;
   if (m->d_coef) (void)hipFree(m->d_coef);
   if (m->d_pts) (void)hipFree(m->d_pts);
+  if (m->d_xyz) (void)hipFree(m->d_xyz);
   if (m->d_cells) (void)hipFree(m->d_cells);
   if (m->d_model) (void)hipFree(m->d_model);
   for (auto &sl : m->slot) {
@@ -157,6 +162,7 @@ extern "C" void srt_model_destroy(srt_model *m) {
       if (sl.d_ids[k]) (void)hipFree(sl.d_ids[k]);
     }
     if (sl.d_sorttmp) (void)hipFree(sl.d_sorttmp);
+    if (sl.d_stage) (void)hipFree(sl.d_stage);
     if (sl.ev0) (void)hipEventDestroy(sl.ev0);
     if (sl.ev1) (void)hipEventDestroy(sl.ev1);
   }
@@ -686,17 +692,23 @@ extern "C" int srt_model_create_scattered_file(const char *ptsfile, int yearday,
   srt_model *m = new srt_model;
   m->kind = 4;
   m->nspec = h.nspec;
+  std::vector<double> xyz(3 * (size_t)h.npts);
+  for (size_t i = 0; i < (size_t)h.npts; ++i)
+    for (int c = 0; c < 3; ++c) xyz[(size_t)c * h.npts + i] = h.pts[8 * i + c];
   hipError_t e = hipMalloc(&m->d_pts, h.pts.size() * sizeof(double));
   if (e == hipSuccess) e = hipMalloc(&m->d_cells, h.cell_start.size() * sizeof(int));
+  if (e == hipSuccess) e = hipMalloc(&m->d_xyz, xyz.size() * sizeof(double));
+  if (e == hipSuccess) e = hipMemcpy(m->d_xyz, xyz.data(), xyz.size() * sizeof(double), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(m->d_pts, h.pts.data(), h.pts.size() * sizeof(double), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(m->d_cells, h.cell_start.data(), h.cell_start.size() * sizeof(int), hipMemcpyHostToDevice);
   if (e != hipSuccess) {
     srt_model_destroy(m);
     return srt_set_error(e == hipErrorOutOfMemory ? SRT_ENOMEM : SRT_EDEVICE, "scattered model upload: %s", hipGetErrorString(e));
   }
-  m->device_bytes = (int64_t)(h.pts.size() * sizeof(double) + h.cell_start.size() * sizeof(int));
+  m->device_bytes = (int64_t)((h.pts.size() + xyz.size()) * sizeof(double) + h.cell_start.size() * sizeof(int));
   ScatteredModel &s = m->scat;
   s.pts = m->d_pts;
+  s.xyz = m->d_xyz;
   s.cell_start = m->d_cells;
   for (int k = 0; k < 3; ++k) {
     s.origin[k] = h.origin[k];
@@ -733,6 +745,16 @@ struct DevBuf {
   }
   int alloc(size_t n) { return hipMalloc(&p, n * sizeof(double)) == hipSuccess ? 0 : -1; }
 };
+
+// scattered model: staging records for the one-wave blocks serving n items (srt_scattered.hpp shared_fit); beyond
+// 4096 blocks (2 GiB) the kernels run without (own-list path)
+static void stage_alloc(DevBuf &b, int64_t n) {
+  const int64_t blocks = (n + WAVE - 1) / WAVE;
+  if (blocks > 4096 || b.alloc((size_t)blocks * ScatteredModel::REC_CAP * ScatteredModel::REC)) {
+    b.p = nullptr;
+    (void)hipGetLastError();
+  }
+}
 
 static int upload(DevBuf &b, const double *h, size_t n) {
   if (b.alloc(n)) return srt_set_error(SRT_ENOMEM, "hipMalloc failed");
@@ -813,11 +835,15 @@ extern "C" int srt_gradients(srt_model *m, int64_t n, const double *x, const dou
   if ((rc = upload(dx, x, 3 * n)) || (rc = upload(dk, k, 3 * n)) || (rc = upload(dw, w, n))) return rc;
   if (dout.alloc(14 * n)) return srt_set_error(SRT_ENOMEM, "hipMalloc failed");
   if (m->kind == 1)
-    launch_wave_blocks(gradients_kernel<NgoModel, false>, n, 0, (const NgoModel *)m->d_model, (const Common *)m->d_common, (long long)n, (const double *)dx.p, (const double *)dk.p, (const double *)dw.p, del, dout.p);
+    launch_wave_blocks(gradients_kernel<NgoModel, false>, n, 0, (const NgoModel *)m->d_model, (const Common *)m->d_common, (long long)n, (const double *)dx.p, (const double *)dk.p, (const double *)dw.p, del, dout.p, (double *)nullptr);
   else if (m->kind == 3)
-    launch_wave_blocks(gradients_kernel<InterpModel, true>, n, 0, (const InterpModel *)m->d_model, (const Common *)m->d_common, (long long)n, (const double *)dx.p, (const double *)dk.p, (const double *)dw.p, del, dout.p);
-  else if (m->kind == 4)
-    launch_wave_blocks(gradients_kernel<ScatteredModel, true>, n, 0, (const ScatteredModel *)m->d_model, (const Common *)m->d_common, (long long)n, (const double *)dx.p, (const double *)dk.p, (const double *)dw.p, del, dout.p);
+    launch_wave_blocks(gradients_kernel<InterpModel, true>, n, 0, (const InterpModel *)m->d_model, (const Common *)m->d_common, (long long)n, (const double *)dx.p, (const double *)dk.p, (const double *)dw.p, del, dout.p, (double *)nullptr);
+  else if (m->kind == 4) {
+    DevBuf stage;
+    stage_alloc(stage, n);
+    launch_wave_blocks(gradients_kernel<ScatteredModel, true>, n, 0, (const ScatteredModel *)m->d_model, (const Common *)m->d_common, (long long)n, (const double *)dx.p, (const double *)dk.p, (const double *)dw.p, del, dout.p, stage.p);
+    HIP_OK(hipDeviceSynchronize()); // `stage` is freed at the end of this scope
+  }
   else return srt_set_error(SRT_EINVAL, "model kind %d unsupported", m->kind);
   HIP_OK(hipMemcpy(out, dout.p, 14 * n * sizeof(double), hipMemcpyDeviceToHost));
   return SRT_OK;
@@ -832,11 +858,15 @@ extern "C" int srt_rk_step(srt_model *m, int64_t n, const double *args, const do
   if ((rc = upload(da, args, 7 * n)) || (rc = upload(dd, dt, n))) return rc;
   if (dout.alloc(21 * n)) return srt_set_error(SRT_ENOMEM, "hipMalloc failed");
   if (m->kind == 1)
-    launch_wave_blocks(rkstep_kernel<NgoModel, false>, n, 0, (const NgoModel *)m->d_model, (const Common *)m->d_common, (long long)n, (const double *)da.p, (const double *)dd.p, del, dout.p);
+    launch_wave_blocks(rkstep_kernel<NgoModel, false>, n, 0, (const NgoModel *)m->d_model, (const Common *)m->d_common, (long long)n, (const double *)da.p, (const double *)dd.p, del, dout.p, (double *)nullptr);
   else if (m->kind == 3)
-    launch_wave_blocks(rkstep_kernel<InterpModel, true>, n, 0, (const InterpModel *)m->d_model, (const Common *)m->d_common, (long long)n, (const double *)da.p, (const double *)dd.p, del, dout.p);
-  else if (m->kind == 4)
-    launch_wave_blocks(rkstep_kernel<ScatteredModel, true>, n, 0, (const ScatteredModel *)m->d_model, (const Common *)m->d_common, (long long)n, (const double *)da.p, (const double *)dd.p, del, dout.p);
+    launch_wave_blocks(rkstep_kernel<InterpModel, true>, n, 0, (const InterpModel *)m->d_model, (const Common *)m->d_common, (long long)n, (const double *)da.p, (const double *)dd.p, del, dout.p, (double *)nullptr);
+  else if (m->kind == 4) {
+    DevBuf stage;
+    stage_alloc(stage, n);
+    launch_wave_blocks(rkstep_kernel<ScatteredModel, true>, n, 0, (const ScatteredModel *)m->d_model, (const Common *)m->d_common, (long long)n, (const double *)da.p, (const double *)dd.p, del, dout.p, stage.p);
+    HIP_OK(hipDeviceSynchronize());
+  }
   else return srt_set_error(SRT_EINVAL, "model kind %d unsupported", m->kind);
   HIP_OK(hipMemcpy(out, dout.p, 21 * n * sizeof(double), hipMemcpyDeviceToHost));
   return SRT_OK;
@@ -1172,6 +1202,18 @@ extern "C" int srt_trace_batch_device(srt_model *m, const srt_params *p, int64_t
     HIP_OK(hipcub::DeviceRadixSort::SortPairs(sl.d_sorttmp, tb, sl.d_keys[0], sl.d_keys[1], sl.d_ids[0], sl.d_ids[1], (int)nrays, 0, 30, st));
     a.order = sl.d_ids[1];
   }
+  a.scratch = nullptr;
+  if (m->kind == 4) { // without the buffer the kernel still runs (own-list path everywhere), only slower
+    if (grid > sl.stage_blocks) {
+      if (sl.used) HIP_OK(hipEventSynchronize(sl.ev1));
+      if (sl.d_stage) (void)hipFree(sl.d_stage);
+      sl.d_stage = nullptr;
+      sl.stage_blocks = 0;
+      if (hipMalloc(&sl.d_stage, (size_t)grid * ScatteredModel::REC_CAP * ScatteredModel::REC * sizeof(double)) == hipSuccess) sl.stage_blocks = grid;
+      else (void)hipGetLastError();
+    }
+    a.scratch = sl.d_stage;
+  }
   const bool fixed = p->fixedstep != 0, igrf = m->cm.fld.use_igrf != 0 || m->cm.fld.use_tsy != 0;
   // one instantiation per (model, integrator, field option): the dipole kernels carry none of the IGRF code
 #define SRT_LAUNCH_TRACE(MODEL, LDS)                                                                                             \
@@ -1190,6 +1232,18 @@ extern "C" int srt_trace_batch_device(srt_model *m, const srt_params *p, int64_t
 #undef SRT_LAUNCH_TRACE
   HIP_OK(hipGetLastError());
   HIP_OK(hipEventRecord(sl.ev1, st));
+#ifdef SRT_PHASE_TIMING
+  if (m->kind == 4 && getenv("SRT_PHASE_TIMING")) {
+    unsigned long long h[16];
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipMemcpyFromSymbol(h, HIP_SYMBOL(srt_phase_cycles), sizeof h));
+    fprintf(stderr, "srt phase cycles:");
+    for (int i = 0; i < 16; ++i) fprintf(stderr, " %llu", h[i]);
+    fprintf(stderr, "\n");
+    memset(h, 0, sizeof h);
+    HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(srt_phase_cycles), h, sizeof h));
+  }
+#endif
   sl.used = true;
   m->last_slot = m->next_slot;
   m->next_slot = (m->next_slot + 1) % srt_model::NSLOT;

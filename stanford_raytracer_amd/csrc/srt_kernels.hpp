@@ -26,6 +26,7 @@ struct TraceArgs {
   int *nrows;         // [nrays]
   int *stopcond;      // [nrays]
   unsigned long long *counters; // [0] queue head, [1] accepted steps, [2] attempts, [3] wave-attempts (loop trips of all waves)
+  double *scratch;    // scattered model: staging records, ScatteredModel::REC_CAP * REC doubles per block (or nullptr)
   TraceParams p;
 };
 
@@ -223,6 +224,7 @@ __global__ __launch_bounds__(64) void trace_kernel(const M *__restrict__ mp, con
   const CM &cm = *static_cast<const CM *>(cp);
   __shared__ __attribute__((aligned(16))) double tile[USE_LDS ? TILE_DOUBLES : 2];
   double *lds = USE_LDS ? tile : nullptr;
+  bind_scratch(m, lds, a.scratch);
   const TraceParams &P = a.p;
   const int lane = threadIdx.x;
   const Tableau &tab = FIXED ? TAB_RK4 : TAB_RKF45;
@@ -567,10 +569,11 @@ __global__ void handedness_kernel(long long n, const double *in, int *out) {
 template <class M, bool USE_LDS>
 __global__ __launch_bounds__(64) void gradients_kernel(const M *__restrict__ mp, const Common *__restrict__ cp, long long n, const double *x,
                                                        const double *k, const double *w, double del,
-                                                       double *out) {
+                                                       double *out, double *scratch) {
   const M &m = *mp;
   const Common &cm = *cp;
   __shared__ __attribute__((aligned(16))) double tile[USE_LDS ? TILE_DOUBLES : 2];
+  bind_scratch(m, USE_LDS ? tile : nullptr, scratch);
   long long i = (long long)blockIdx.x * WAVE + threadIdx.x;
   long long j = i < n ? i : n - 1;
   double st[6] = {x[3 * j], x[3 * j + 1], x[3 * j + 2], k[3 * j], k[3 * j + 1], k[3 * j + 2]};
@@ -604,10 +607,11 @@ __global__ __launch_bounds__(64) void gradients_kernel(const M *__restrict__ mp,
 // out[n][21] = rk4(7), rk45 4th(7), rk45 5th(7)
 template <class M, bool USE_LDS>
 __global__ __launch_bounds__(64) void rkstep_kernel(const M *__restrict__ mp, const Common *__restrict__ cp, long long n, const double *args,
-                                                    const double *dtv, double del, double *out) {
+                                                    const double *dtv, double del, double *out, double *scratch) {
   const M &m = *mp;
   const Common &cm = *cp;
   __shared__ __attribute__((aligned(16))) double tile[USE_LDS ? TILE_DOUBLES : 2];
+  bind_scratch(m, USE_LDS ? tile : nullptr, scratch);
   long long i = (long long)blockIdx.x * WAVE + threadIdx.x;
   long long j = i < n ? i : n - 1;
   double st[6];

@@ -20,6 +20,10 @@ constexpr int TILE_PAD_BYTES = 2048;
 constexpr int TILE_DOUBLES = (RING * UNIT_BYTES + TILE_PAD_BYTES) / 8;
 
 typedef double d2_t __attribute__((ext_vector_type(2)));
+
+// Per-launch device scratch of a model (only the scattered model has any: srt_scattered.hpp overloads this).
+template <class M>
+__device__ __forceinline__ void bind_scratch(const M &, double *, double *) {}
 #define SRT_AS1 __attribute__((address_space(1)))
 #define SRT_AS3 __attribute__((address_space(3)))
 
