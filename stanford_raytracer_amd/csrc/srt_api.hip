@@ -746,11 +746,18 @@ struct DevBuf {
   int alloc(size_t n) { return hipMalloc(&p, n * sizeof(double)) == hipSuccess ? 0 : -1; }
 };
 
+// SRT_SCATTERED_STAGING=0 in the environment: no staging buffer, i.e. the own-list path for every stencil (tests hold
+// the two paths against each other)
+static bool staging_enabled() {
+  const char *e = getenv("SRT_SCATTERED_STAGING");
+  return !(e && e[0] == '0');
+}
+
 // scattered model: staging records for the one-wave blocks serving n items (srt_scattered.hpp shared_fit); beyond
 // 4096 blocks (2 GiB) the kernels run without (own-list path)
 static void stage_alloc(DevBuf &b, int64_t n) {
   const int64_t blocks = (n + WAVE - 1) / WAVE;
-  if (blocks > 4096 || b.alloc((size_t)blocks * ScatteredModel::REC_CAP * ScatteredModel::REC)) {
+  if (!staging_enabled() || blocks > 4096 || b.alloc((size_t)blocks * ScatteredModel::REC_CAP * ScatteredModel::REC)) {
     b.p = nullptr;
     (void)hipGetLastError();
   }
@@ -1203,7 +1210,7 @@ extern "C" int srt_trace_batch_device(srt_model *m, const srt_params *p, int64_t
     a.order = sl.d_ids[1];
   }
   a.scratch = nullptr;
-  if (m->kind == 4) { // without the buffer the kernel still runs (own-list path everywhere), only slower
+  if (m->kind == 4 && staging_enabled()) { // without the buffer the kernel still runs (own-list path everywhere), only slower
     if (grid > sl.stage_blocks) {
       if (sl.used) HIP_OK(hipEventSynchronize(sl.ev1));
       if (sl.d_stage) (void)hipFree(sl.d_stage);

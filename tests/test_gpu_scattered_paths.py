@@ -1,0 +1,122 @@
+"""modelnum 4 on the device: the two cooperative stencil paths held against each other and against the CPU oracle.
+
+shared path  = one candidate scan for the whole stencil, staged neighbour records, the weights of the six offset points
+               from the centre's transcendental values by series (srt_scattered.hpp shared_fit)
+own-list path = every stencil point scans for itself and evaluates etainv() per (point, neighbour) (own_fit); taken
+               when there is no staging buffer (SRT_SCATTERED_STAGING=0), the stencil straddles a grid cell, ...
+"direct" samples = samples so close to the centre that the series' bounds do not hold: their weights are evaluated by
+               etainv() itself on the shared path.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_DIR, vrel
+
+pytestmark = pytest.mark.gpu
+
+
+def _own_list(fn):
+    """Run fn() with the staging buffer switched off (own-list path for every stencil)."""
+    os.environ["SRT_SCATTERED_STAGING"] = "0"
+    try:
+        return fn()
+    finally:
+        del os.environ["SRT_SCATTERED_STAGING"]
+
+
+def _states(oracle_model, n, seed, scale=0.9):
+    from stanford_raytracer_amd import workloads as wl
+
+    pos, d, w = wl.launch_set(n, seed)
+    pos = pos * scale
+    od = np.array([oracle_model.disp(p, dd, ww) for p, dd, ww in zip(pos, d, w)])
+    ok = od[:, 8] > 0
+    return pos[ok], od[ok, 8:9] * d[ok], w[ok]
+
+
+def test_shared_and_own_list_paths_agree(gpu_models, oracle_scattered):
+    """Same stencils through both paths: the right-hand sides agree far inside the amplification of the 10 m stencil
+    (differences of ln N at 1e-16 relative are divided by 1e-6 |x|)."""
+    g = gpu_models["scattered"]
+    x, k, w = _states(oracle_scattered, 400, 4242)
+    a = g.gradients(x, k, w, 1e-6)
+    b = _own_list(lambda: g.gradients(x, k, w, 1e-6))
+    assert np.isfinite(a).all() and np.isfinite(b).all()
+    assert vrel(a[:, 0:3], b[:, 0:3]).max() <= 1e-9                      # dF/dk: densities at the centre only
+    e = vrel(a[:, 4:7], b[:, 4:7])
+    assert np.median(e) <= 1e-6 and np.percentile(e, 90) <= 1e-4         # dF/dx: d(ln N) over the stencil
+    # one RK45 step, positions
+    args = np.concatenate([x, k, w[:, None]], axis=1)[:120]
+    dt = np.full(len(args), 1e-3)
+    sa = g.rk_step(args, dt, 1e-6)
+    sb = _own_list(lambda: g.rk_step(args, dt, 1e-6))
+    es = vrel(sa[:, 14:17], sb[:, 14:17])            # the stages see k advanced by dt * (dF/dx)/(dF/dw): same yardstick as G3
+    assert np.median(es) <= 1e-8 and np.percentile(es, 90) <= 1e-6
+
+
+@pytest.mark.parametrize("offset_m", [30.0, 300.0, 3.0e4])
+def test_samples_next_to_the_query_point(gpu_models, oracle_scattered, offset_m):
+    """Query points a few stencil widths away from a sample: that sample's weight cannot come from the series (its
+    distance changes by a large fraction across the stencil) and is evaluated directly; the others still use the
+    series.  Held against the oracle and against the own-list path."""
+    from stanford_raytracer_amd import workloads as wl
+
+    g = gpu_models["scattered"]
+    pts = np.load(os.path.join(GOLDEN_DIR, "points5500.npz"))["pts"]
+    r = np.linalg.norm(pts, axis=1)
+    sel = pts[(r > 1.3 * wl.R_E) & (r < 4.0 * wl.R_E)][:150]
+    rng = np.random.default_rng(7)
+    u = rng.normal(size=sel.shape)
+    x = sel + offset_m * u / np.linalg.norm(u, axis=1, keepdims=True)
+    _, d, w = wl.launch_set(len(x), 77)
+    od = np.array([oracle_scattered.disp(p, dd, ww) for p, dd, ww in zip(x, d, w)])
+    ok = od[:, 8] > 0
+    x, k, w = x[ok][:80], (od[ok, 8:9] * d[ok])[:80], w[ok][:80]
+    assert len(x) >= 40
+    a = g.gradients(x, k, w, 1e-6)
+    b = _own_list(lambda: g.gradients(x, k, w, 1e-6))
+    o = np.array([oracle_scattered.grad(p, kk, ww, 1e-6) for p, kk, ww in zip(x, k, w)])
+    assert vrel(a[:, 0:3], o[:, 0:3]).max() <= 1e-7 and vrel(a[:, 0:3], b[:, 0:3]).max() <= 1e-9
+    for other in (b, o):
+        e = vrel(a[:, 4:7], other[:, 4:7])
+        assert np.median(e) <= 1e-5 and np.percentile(e, 90) <= 1e-3
+
+
+def test_exact_window_goes_through_the_direct_weights(pointsfile):
+    """scattered_interp_exact=1 has no series: every sample of the shared path is direct.  Same answers as the
+    own-list path, and the per-lane evaluation of funcPlasmaParams."""
+    from oracle import oracle
+    from stanford_raytracer_amd import api
+
+    kw = dict(exact=1, local_window_scale=2.0)
+    g = api.Model.scattered_file(pointsfile, **kw)
+    o = oracle.Model.scattered_file(pointsfile, perm_seed=2 | 0x80000000, **kw)
+    x, k, w = _states(o, 200, 99)
+    x, k, w = x[:60], k[:60], w[:60]
+    a = g.gradients(x, k, w, 1e-6)
+    b = _own_list(lambda: g.gradients(x, k, w, 1e-6))
+    og = np.array([o.grad(p, kk, ww, 1e-6) for p, kk, ww in zip(x, k, w)])
+    assert vrel(a[:, 0:3], b[:, 0:3]).max() <= 1e-9 and vrel(a[:, 0:3], og[:, 0:3]).max() <= 1e-7
+    e = vrel(a[:, 4:7], b[:, 4:7])
+    assert np.median(e) <= 1e-6 and np.percentile(e, 90) <= 1e-4
+
+
+def test_trace_is_the_same_with_and_without_staging(gpu_models):
+    """A short adaptive launch through both paths: launch rows identical, fates and row totals agree."""
+    from stanford_raytracer_amd import workloads as wl
+
+    g = gpu_models["scattered"]
+    pos, d, w = wl.launch_set(256, 31)
+    pos = pos * 0.9
+    kw = dict(fixedstep=0, dt0=1e-3, dtmax=0.1, tmax=0.05, maxerr=5e-4, maxsteps=60, del_=1e-6, outputper=1)
+    ra, na, sa, _ = g.trace(pos, d, w, **kw)
+    rb, nb, sb, _ = _own_list(lambda: g.trace(pos, d, w, **kw))
+    both = (na > 1) & (nb > 1)
+    assert both.sum() >= 100
+    assert np.array_equal(ra[both, 0, 1:4], rb[both, 0, 1:4])
+    assert vrel(ra[both, 0, 16:20], rb[both, 0, 16:20]).max() <= 1e-12      # densities on the launch row
+    assert np.median(vrel(ra[both, 1, 1:4], rb[both, 1, 1:4])) <= 1e-8       # after the first step
+    assert np.mean(sa == sb) >= 0.95
+    assert abs(int(na.sum()) - int(nb.sum())) <= 0.05 * nb.sum()
