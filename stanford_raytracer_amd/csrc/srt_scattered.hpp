@@ -11,6 +11,7 @@
 //   A = sum_i w_i m_i m_i^T,  b_s = sum_i w_i m_i lnN_s(i),  w_i = 0.5*etainv(r_i) (= dinv_i^2), m_i = monomials(x_i - x)
 //   solve A y = e_1 (Cholesky, dposv 'U'), ln N_s(x) = y . b_s           [== dot(aa, vals) with aa = (E y) * dinv]
 #pragma once
+#include <utility>
 #include "srt_models.hpp"
 
 namespace srt {
@@ -57,6 +58,74 @@ __device__ unsigned long long srt_phase_cycles[16];
 #define SRT_PHASE_ZERO(ldsbase) do {} while (0)
 #define SRT_PHASE_FLUSH(ldsbase) do {} while (0)
 #endif
+
+// Order 2 on the shared path: A = sum w m m^T has 55 entries but only 35 different sums -- the moments sum w x^a y^b z^c,
+// a + b + c <= 4 (m_a m_c is a monomial of degree <= 4).  35 + 40 running sums fit the 256 vector registers next to the
+// record being folded in; 55 + 40 do not (the rest would sit in accumulation registers and be copied in and out per
+// neighbour).  Monomials by degree; MOM_E[i] = exponents of x, y, z.
+struct Moments {
+  static constexpr int N = 35;
+  static constexpr int E[N][3] = {{0, 0, 0}, {1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {2, 0, 0}, {1, 1, 0}, {1, 0, 1}, {0, 2, 0}, {0, 1, 1},
+                                  {0, 0, 2}, {3, 0, 0}, {2, 1, 0}, {2, 0, 1}, {1, 2, 0}, {1, 1, 1}, {1, 0, 2}, {0, 3, 0}, {0, 2, 1},
+                                  {0, 1, 2}, {0, 0, 3}, {4, 0, 0}, {3, 1, 0}, {3, 0, 1}, {2, 2, 0}, {2, 1, 1}, {2, 0, 2}, {1, 3, 0},
+                                  {1, 2, 1}, {1, 1, 2}, {1, 0, 3}, {0, 4, 0}, {0, 3, 1}, {0, 2, 2}, {0, 1, 3}, {0, 0, 4}};
+  static constexpr int find(int a, int b, int c) {
+    for (int i = 0; i < N; ++i)
+      if (E[i][0] == a && E[i][1] == b && E[i][2] == c) return i;
+    return -1;
+  }
+  // the monomial is its parent times one coordinate: the last non-zero exponent (z, else y, else x) reduced by one
+  static constexpr int axis(int i) { return E[i][2] > 0 ? 2 : (E[i][1] > 0 ? 1 : 0); }
+  static constexpr int parent(int i) {
+    return axis(i) == 2 ? find(E[i][0], E[i][1], E[i][2] - 1) : (axis(i) == 1 ? find(E[i][0], E[i][1] - 1, 0) : find(E[i][0] - 1, 0, 0));
+  }
+  // tabular_monomials of order 2 (lsinterp_mod.f95:70-99): exponents (x, y, z) of m_0 .. m_9
+  static constexpr int ME[10][3] = {{0, 0, 0}, {0, 0, 1}, {0, 0, 2}, {0, 1, 0}, {0, 1, 1}, {0, 2, 0}, {1, 0, 0}, {1, 0, 1}, {1, 1, 0}, {2, 0, 0}};
+  static constexpr int of_m(int a) { return find(ME[a][0], ME[a][1], ME[a][2]); }
+  static constexpr int of_pair(int a, int c) { return find(ME[a][0] + ME[c][0], ME[a][1] + ME[c][1], ME[a][2] + ME[c][2]); }
+  // packed upper triangle t -> (a, c), row a holds A[a][a..9]
+  static constexpr int row_of(int t) {
+    int a = 0;
+    while (t >= 10 - a) {
+      t -= 10 - a;
+      ++a;
+    }
+    return a;
+  }
+  static constexpr int col_of(int t) {
+    int a = 0;
+    while (t >= 10 - a) {
+      t -= 10 - a;
+      ++a;
+    }
+    return a + t;
+  }
+  template <int I>
+  struct C { // compile-time constants of moment I / packed entry I
+    static constexpr int par = parent(I), ax = axis(I);
+  };
+  template <int T>
+  struct P {
+    static constexpr int mom = of_pair(row_of(T), col_of(T));
+  };
+  template <int A>
+  struct M1 {
+    static constexpr int mom = of_m(A);
+  };
+  template <int... I>
+  __device__ __forceinline__ static void monomials(double (&mono)[N], const double (&d)[3], std::integer_sequence<int, I...>) {
+    mono[0] = 1.0;
+    ((mono[I + 1] = mono[C<I + 1>::par] * d[C<I + 1>::ax]), ...);
+  }
+  template <int... T>
+  __device__ __forceinline__ static void expand(const double (&M)[N], double (&A)[55], std::integer_sequence<int, T...>) {
+    ((A[T] = M[P<T>::mom]), ...);
+  }
+  template <int... A>
+  __device__ __forceinline__ static void firsts(const double (&mono)[N], double (&m)[10], std::integer_sequence<int, A...>) {
+    ((m[A] = mono[M1<A>::mom]), ...);
+  }
+};
 
 struct ScatteredModel {
   const double *pts;     // [npts][8]: x, y, z, lnN[4], nearest-sample distance
@@ -611,6 +680,7 @@ struct ScatteredModel {
     // ---- pass 2: normal equations.  Group g walks the records for point g, its 8 lanes splitting them; no
     // transcendental function and no branch in the loop
     double A[NT], b[J][4];
+    double Mm[J == 10 ? Moments::N : 1]; // order 2: the 35 moments stand in for the 55 entries of A while summing
     int kept = 0;
     bool usemask = true, todo = fit;
     const double eta1 = 1.0 + eta;
@@ -623,6 +693,8 @@ struct ScatteredModel {
 #pragma unroll
         for (int t = 0; t < NT; ++t) A[t] = 0.0;
 #pragma unroll
+        for (int t = 0; t < (J == 10 ? Moments::N : 1); ++t) Mm[t] = 0.0;
+#pragma unroll
         for (int a = 0; a < J; ++a)
 #pragma unroll
           for (int s = 0; s < 4; ++s) b[a][s] = 0.0;
@@ -630,16 +702,32 @@ struct ScatteredModel {
       }
       double pw2 = 0.0, pd0 = 0.0, pd1 = 0.0, pd2 = 0.0, pln[4] = {0.0, 0.0, 0.0, 0.0}; // the record waiting to be folded in
       auto fold = [&](double w2, double d0, double d1, double d2, const double (&ln)[4]) {
-        double m[J];
-        monomials<J>(d0, d1, d2, m);
-        int t = 0;
+        if constexpr (J == 10) {
+          const double dd[3] = {d0, d1, d2};
+          double mono[Moments::N], m[10];
+          Moments::monomials(mono, dd, std::make_integer_sequence<int, Moments::N - 1>{});
+          Mm[0] += w2;
 #pragma unroll
-        for (int a = 0; a < J; ++a) {
-          double wa = w2 * m[a];
+          for (int i = 1; i < Moments::N; ++i) Mm[i] += w2 * mono[i];
+          Moments::firsts(mono, m, std::make_integer_sequence<int, 10>{}); // m_a: the same products as monomials<10>()
 #pragma unroll
-          for (int cI = a; cI < J; ++cI) A[t++] += wa * m[cI];
+          for (int a = 0; a < 10; ++a) {
+            double wa = w2 * m[a];
 #pragma unroll
-          for (int s = 0; s < 4; ++s) b[a][s] += wa * ln[s];
+            for (int s = 0; s < 4; ++s) b[a][s] += wa * ln[s];
+          }
+        } else {
+          double m[J];
+          monomials<J>(d0, d1, d2, m);
+          int t = 0;
+#pragma unroll
+          for (int a = 0; a < J; ++a) {
+            double wa = w2 * m[a];
+#pragma unroll
+            for (int cI = a; cI < J; ++cI) A[t++] += wa * m[cI];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) b[a][s] += wa * ln[s];
+          }
         }
       };
       // The records come back through a ring of four 64-record buffers in LDS (the list area: the list is dead by now),
@@ -693,6 +781,8 @@ struct ScatteredModel {
                            : "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(c3), "=&v"(c4), "=&v"(c5), "=&v"(c6), "=&v"(wdir)
                            : "v"(ra), "v"(ra + slot_off)
                            : "memory");
+              // the sums of the PREVIOUS record (independent of this record's weight, which is one long dependent chain)
+              fold(pw2, pd0, pd1, pd2, pln);
               const double d0 = c0.x - p[0], d1 = c0.y - p[1], d2 = c1.x - p[2];
               const double ss = d0 * d0 + d1 * d1 + d2 * d2;
               // series from the centre's values ([8] r_c [9] inv [10] ca [11] sa [12] u_c [13] E_c)
@@ -711,11 +801,7 @@ struct ScatteredModel {
               // strictly inside (kdtree_mod.f95:171; the shared list holds a superset); :316-317
               const bool use = k < n_list && ss < r2 && !(usemask && !(e > 1.0e-16));
               kept += use ? 1 : 0;
-              // Two-stage software pipeline: the sums of the PREVIOUS record are added while this record's weight is
-              // worked out -- the weight is one long dependent chain (sqrt, two series), the 105 multiply-adds are
-              // independent of it, and with one wave per SIMD only instructions of this wave can fill its bubbles.
-              // Same records in the same order: the sums do not change.
-              fold(pw2, pd0, pd1, pd2, pln);
+              // (this record waits for the next trip's reads: same records in the same order, the sums do not change)
               pw2 = use ? 0.5 * e : 0.0;
               pd0 = d0, pd1 = d1, pd2 = d2;
               pln[0] = c1.y, pln[1] = c2.x, pln[2] = c2.y, pln[3] = c3.x;
@@ -737,8 +823,14 @@ struct ScatteredModel {
     // combine the 8 lanes' partial sums and solve
     fi.v[0] = fi.v[1] = fi.v[2] = fi.v[3] = 0.0;
     if (__any(fit)) {
+      if constexpr (J == 10) {
 #pragma unroll
-      for (int t = 0; t < NT; ++t) A[t] = group_sum(A[t]);
+        for (int t = 0; t < Moments::N; ++t) Mm[t] = group_sum(Mm[t]);
+        Moments::expand(Mm, A, std::make_integer_sequence<int, 55>{});
+      } else {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) A[t] = group_sum(A[t]);
+      }
 #pragma unroll
       for (int a = 0; a < J; ++a)
 #pragma unroll
