@@ -1056,17 +1056,26 @@ struct ScatteredModel {
         SRT_PHASE_ADD(11, hi9[0] - lo9[0] + hi9[1] - lo9[1] + hi9[2] - lo9[2] + hi9[3] - lo9[3] + hi9[4] - lo9[4] + hi9[5] - lo9[5] + hi9[6] - lo9[6] + hi9[7] - lo9[7] + hi9[8] - lo9[8]);
         SRT_PHASE(15);
         const SRT_AS1 double *xs = M.gxyz(), *ys = xs + M.npts, *zs = ys + M.npts;
+        // (one trip ahead: the next 27 loads are in flight while this trip's samples are tested and compacted)
+        int idxn[9];
+        double qxn[9], qyn[9], qzn[9];
+        auto fetch = [&](int t0) {
+#pragma unroll
+          for (int r = 0; r < 9; ++r) {
+            const int i = lo9[r] + t0 + lane;
+            idxn[r] = i < hi9[r] ? i : -1;
+            const int ic = idxn[r] < 0 ? 0 : idxn[r];
+            qxn[r] = xs[ic], qyn[r] = ys[ic], qzn[r] = zs[ic];
+          }
+        };
+        if (maxlen > 0) fetch(0);
 #pragma unroll 1
         for (int t0 = 0; t0 < maxlen; t0 += 64) {
           int idx[9];
           double qx[9], qy[9], qz[9];
 #pragma unroll
-          for (int r = 0; r < 9; ++r) {
-            const int i = lo9[r] + t0 + lane;
-            idx[r] = i < hi9[r] ? i : -1;
-            const int ic = idx[r] < 0 ? 0 : idx[r];
-            qx[r] = xs[ic], qy[r] = ys[ic], qz[r] = zs[ic];
-          }
+          for (int r = 0; r < 9; ++r) idx[r] = idxn[r], qx[r] = qxn[r], qy[r] = qyn[r], qz[r] = qzn[r];
+          if (t0 + 64 < maxlen) fetch(t0 + 64);
 #pragma unroll
           for (int r = 0; r < 9; ++r) {
             const double d0 = qx[r] - pc[0], d1 = qy[r] - pc[1], d2 = qz[r] - pc[2];
