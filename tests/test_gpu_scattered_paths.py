@@ -120,3 +120,35 @@ def test_trace_is_the_same_with_and_without_staging(gpu_models):
     assert np.median(vrel(ra[both, 1, 1:4], rb[both, 1, 1:4])) <= 1e-8       # after the first step
     assert np.mean(sa == sb) >= 0.95
     assert abs(int(na.sum()) - int(nb.sum())) <= 0.05 * nb.sum()
+
+
+def test_paths_agree_on_the_full_size_sample_set(tmp_path):
+    """BASELINE config[4]'s own sample set (825 k samples, up to ~2 000 neighbours per lookup: dozens of ring buffers
+    per stencil, lists near the staging capacity): shared path against own-list path on launch points of that workload,
+    and against the per-lane evaluation of funcPlasmaParams at the centre."""
+    from stanford_raytracer_amd import api, workloads as wl
+
+    pts, lnN = wl.make_points_config5(5)
+    pfile = str(tmp_path / "points825k.txt")
+    wl.write_points_file(pfile, pts, lnN, np.array([-10.0 * wl.R_E, 10.0 * wl.R_E] * 3))
+    g = api.Model.scattered_file(pfile, window_scale=1.5, order=2, exact=0, local_window_scale=5.0)
+    pos, d, w = wl.launch_set(1536, 5)
+    disp = g.dispersion(pos, d * 1e-3, w)                    # columns 6.. : the roots' k
+    kmag = np.where(disp[:, 8] > 0, disp[:, 8], disp[:, 6])
+    ok = np.isfinite(kmag) & (kmag > 0)
+    x, k, w = pos[ok], kmag[ok, None] * d[ok], w[ok]
+    assert len(x) >= 1000
+    a = g.gradients(x, k, w, 1e-6)
+    b = _own_list(lambda: g.gradients(x, k, w, 1e-6))
+    fin = np.isfinite(a).all(axis=1) & np.isfinite(b).all(axis=1)
+    assert fin.mean() >= 0.99
+    assert vrel(a[fin, 0:3], b[fin, 0:3]).max() <= 1e-8
+    e = vrel(a[fin, 4:7], b[fin, 4:7])
+    assert np.median(e) <= 1e-5 and np.percentile(e, 90) <= 1e-3
+    # a short launch through both paths: same fates
+    kw = dict(fixedstep=0, dt0=1e-3, dtmax=0.1, tmax=0.5, maxerr=5e-4, maxsteps=24, del_=1e-6, outputper=8)
+    ra, na, sa, _ = g.trace(pos[:1024], d[:1024], w[:1024], **kw)
+    rb, nb, sb, _ = _own_list(lambda: g.trace(pos[:1024], d[:1024], w[:1024], **kw))
+    assert np.mean(sa == sb) >= 0.97
+    both = (na > 1) & (nb > 1)
+    assert vrel(ra[both, 0, 16:20], rb[both, 0, 16:20]).max() <= 1e-11
