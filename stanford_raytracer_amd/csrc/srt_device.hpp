@@ -87,6 +87,10 @@ __device__ __forceinline__ double fdiv(double a, double b) {
 //  * The 105 (g, h, rec) terms live in six registers spread over the wave (lane l: terms l and l + 64 in visiting
 //    order), loaded by two coalesced reads per call; term i is a v_readlane with a uniform lane number: no memory
 //    access and no wait inside the loops (a load per term -- scalar or vector -- stalls the wave once per term).
+//    => CALL IN WAVE-UNIFORM CONTROL FLOW ONLY: v_readlane reads a lane's register whether or not the lane is active,
+//    but an inactive lane has not loaded its terms.  (The trace kernel used to synthesise the field at the second
+//    end-point estimate inside `if (!first_attempt)`: stale terms, a wrong error estimate, wrong accept / reject
+//    decisions -- tests/test_igrf.py::test_gpu_igrf_adaptive_step_control_matches_the_oracle.)
 //  * One point per call is a 105-step chain of dependent fp32 operations with one wave per SIMD to hide it behind:
 //    the seven stencil points of a right-hand side are therefore synthesised together (independent chains).
 //  * The Fortran's A(N), B(N) arrays are the running products r^-(n+1), n r^-(n+1): registers, same multiplication chain.

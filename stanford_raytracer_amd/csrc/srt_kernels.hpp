@@ -56,16 +56,22 @@ template <int NP, class CM>
 __device__ __forceinline__ void rhs_from_plasma(const CM &cm, const double x[3], const double k[3], double w,
                                                 const double d[3], const double (&p)[NP][3],
                                                 const double (&Ns)[NP][4], double rhs[6], double dk[3], double &dw,
-                                                double B[3]) {
+                                                double B[3], const double (*Bpre)[3] = nullptr) {
   // use_igrf (wave-uniform): the seven fields are synthesised together (srt_device.hpp igrf_core); dipole: one by one
   const bool igrf = field_is_igrf(cm);
   double Ball[7][3];
   if (igrf) {
-    double p7[7][3];
+    if (Bpre != nullptr) { // the caller has synthesised the stencil's fields already (trace kernel, end-point stencil)
 #pragma unroll
-    for (int i = 0; i < 7; ++i)
-      for (int c = 0; c < 3; ++c) p7[i][c] = p[i][c];
-    bfield_igrf<7>(cm.fld, p7, Ball);
+      for (int i = 0; i < 7; ++i)
+        for (int c = 0; c < 3; ++c) Ball[i][c] = Bpre[i][c];
+    } else {
+      double p7[7][3];
+#pragma unroll
+      for (int i = 0; i < 7; ++i)
+        for (int c = 0; c < 3; ++c) p7[i][c] = p[i][c];
+      bfield_igrf<7>(cm.fld, p7, Ball);
+    }
 #pragma unroll
     for (int c = 0; c < 3; ++c) B[c] = Ball[0][c];
   } else {
@@ -329,7 +335,17 @@ __global__ __launch_bounds__(64) void trace_kernel(const M *__restrict__ mp, con
     PointState ps2;
 #pragma unroll
     for (int s = 0; s < 4; ++s) ps2.Ns[s] = NP_[0][s];
-    bfield(cm, est2[0], est2[1], est2[2], ps2.B);
+    // IGRF / T04 field options: the fields of the whole end-point stencil (its centre est2, the six offsets and est1)
+    // are synthesised together, once -- est2 alone and est1 alone are serial chains with nothing to hide behind, and
+    // the stencil's centre IS est2 (rhs_from_plasma below takes the fields from here)
+    double Bpost[IGRF ? NPOST : 1][3];
+    if constexpr (IGRF) {
+      bfield_igrf<NPOST>(cm.fld, pp, Bpost);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) ps2.B[c] = Bpost[0][c];
+    } else {
+      bfield(cm, est2[0], est2[1], est2[2], ps2.B);
+    }
     ps2.B2 = ps2.B[0] * ps2.B[0] + ps2.B[1] * ps2.B[1] + ps2.B[2] * ps2.B[2];
     ps2.Bmag = sqrt(ps2.B2);
     if (!FIXED) {
@@ -349,7 +365,12 @@ __global__ __launch_bounds__(64) void trace_kernel(const M *__restrict__ mp, con
         PointState ps1;
 #pragma unroll
         for (int s = 0; s < 4; ++s) ps1.Ns[s] = NP_[NPOST - 1][s];
-        bfield(cm, est1[0], est1[1], est1[2], ps1.B);
+        if constexpr (IGRF) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) ps1.B[c] = Bpost[NPOST - 1][c];
+        } else {
+          bfield(cm, est1[0], est1[1], est1[2], ps1.B);
+        }
         ps1.B2 = ps1.B[0] * ps1.B[0] + ps1.B[1] * ps1.B[1] + ps1.B[2] * ps1.B[2];
         ps1.Bmag = sqrt(ps1.B2);
         double d1[3], d2[3];
@@ -409,7 +430,7 @@ __global__ __launch_bounds__(64) void trace_kernel(const M *__restrict__ mp, con
     }
     // first-stage right-hand side at the would-be new state (also yields its group-velocity terms)
     double rn[6], dk[3], dw, Bn[3];
-    rhs_from_plasma<NPOST>(cm, est2, knew, w, dpost, pp, NP_, rn, dk, dw, Bn);
+    rhs_from_plasma<NPOST>(cm, est2, knew, w, dpost, pp, NP_, rn, dk, dw, Bn, IGRF ? Bpost : nullptr);
     if (needinit) {
       // launch state and row 0 (:693-742)
 #pragma unroll

@@ -94,3 +94,29 @@ def test_gpu_igrf_trajectories(gold, cfgfiles):
         assert pos_err[1] <= 1e-8 and pos_err.max() <= 5e-3
         B_err = np.linalg.norm(rows[r, :T, 13:16] - ref[r, :T, 13:16], axis=1) / np.linalg.norm(ref[r, :T, 13:16], axis=1)
         assert B_err[0] <= 2e-6 and B_err.max() <= 5e-3
+
+
+@pytest.mark.gpu
+def test_gpu_igrf_adaptive_step_control_matches_the_oracle(cfgfiles):
+    """Adaptive Ngo rays in the IGRF field: the step-size controller sees the field at BOTH end-point estimates
+    (raytracer.f95:778-788), so the first accept / grow / reject decisions -- the time stamps of the first rows -- must be
+    the oracle's.  (The end-point fields are synthesised together in wave-uniform control flow: the coefficient terms
+    live in registers spread over the wave, and a synthesis inside a divergent branch would read stale lanes.)"""
+    from oracle import oracle
+    from stanford_raytracer_amd import api
+    api.init(0)
+    g = api.Model.ngo(cfgfiles["ngo"], 2010001, 0).set_field(use_igrf=1)
+    o = oracle.Model.ngo(cfgfiles["ngo"], 2010001, 0).set_igrf(2010001, 0)
+    pos, d, w = wl.launch_set(192, 11)
+    kw = dict(fixedstep=0, dt0=1e-3, dtmax=0.1, tmax=0.05, maxerr=5e-4, maxsteps=40, del_=1e-4)
+    rows, nrows, stop, steps = g.trace(pos, d, w, outputper=1, **kw)
+    orows, onrows, ostop, osteps = o.trace(pos, d, w, capacity=40, **kw)
+    both = (nrows > 4) & (onrows > 4)
+    assert both.sum() >= 100
+    same_t = np.all(rows[both, 1:4, 0] == orows[both, 1:4, 0], axis=1)
+    assert same_t.mean() >= 0.9, "time stamps of rows 1-3 agree on only %.0f %% of the rays" % (100 * same_t.mean())
+    assert np.mean(stop == ostop) >= 0.9
+    assert abs(int(steps) - int(osteps)) <= 0.05 * osteps
+    # and twice the same answer
+    rows2, nrows2, _, _ = g.trace(pos, d, w, outputper=1, **kw)
+    assert np.array_equal(nrows, nrows2) and np.array_equal(np.nan_to_num(rows), np.nan_to_num(rows2))
