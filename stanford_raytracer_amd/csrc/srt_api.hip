@@ -1221,22 +1221,29 @@ extern "C" int srt_trace_batch_device(srt_model *m, const srt_params *p, int64_t
     }
     a.scratch = sl.d_stage;
   }
-  const bool fixed = p->fixedstep != 0, igrf = m->cm.fld.use_igrf != 0 || m->cm.fld.use_tsy != 0;
-  // one instantiation per (model, integrator, field option): the dipole kernels carry none of the IGRF code
+  const bool fixed = p->fixedstep != 0;
+  const int fopt = m->cm.fld.use_tsy != 0 ? 2 : (m->cm.fld.use_igrf != 0 ? 1 : 0);
+  // one instantiation per (model, integrator, field option): the dipole kernels carry none of the IGRF code, the
+  // IGRF-alone kernels none of the T04 call sites
+#define SRT_LAUNCH_TRACE1(MODEL, LDS, FIX)                                                                                       \
+  do {                                                                                                                           \
+    if (fopt == 2) hipLaunchKernelGGL((trace_kernel<MODEL, FIX, LDS, 2>), dim3((unsigned)grid), dim3(WAVE), 0, st, dm, dc, a);   \
+    else if (fopt == 1) hipLaunchKernelGGL((trace_kernel<MODEL, FIX, LDS, 1>), dim3((unsigned)grid), dim3(WAVE), 0, st, dm, dc, a); \
+    else hipLaunchKernelGGL((trace_kernel<MODEL, FIX, LDS, 0>), dim3((unsigned)grid), dim3(WAVE), 0, st, dm, dc, a);             \
+  } while (0)
 #define SRT_LAUNCH_TRACE(MODEL, LDS)                                                                                             \
   do {                                                                                                                           \
     const MODEL *dm = (const MODEL *)m->d_model;                                                                                 \
     const Common *dc = (const Common *)m->d_common;                                                                              \
-    if (fixed && igrf) hipLaunchKernelGGL((trace_kernel<MODEL, true, LDS, true>), dim3((unsigned)grid), dim3(WAVE), 0, st, dm, dc, a);        \
-    else if (fixed) hipLaunchKernelGGL((trace_kernel<MODEL, true, LDS, false>), dim3((unsigned)grid), dim3(WAVE), 0, st, dm, dc, a);          \
-    else if (igrf) hipLaunchKernelGGL((trace_kernel<MODEL, false, LDS, true>), dim3((unsigned)grid), dim3(WAVE), 0, st, dm, dc, a);           \
-    else hipLaunchKernelGGL((trace_kernel<MODEL, false, LDS, false>), dim3((unsigned)grid), dim3(WAVE), 0, st, dm, dc, a);                    \
+    if (fixed) SRT_LAUNCH_TRACE1(MODEL, LDS, true);                                                                              \
+    else SRT_LAUNCH_TRACE1(MODEL, LDS, false);                                                                                   \
   } while (0)
   if (m->kind == 1) SRT_LAUNCH_TRACE(NgoModel, false);
   else if (m->kind == 3) SRT_LAUNCH_TRACE(InterpModel, true);
   else if (m->kind == 4) SRT_LAUNCH_TRACE(ScatteredModel, true);
   else return srt_set_error(SRT_EINVAL, "model kind %d unsupported", m->kind);
 #undef SRT_LAUNCH_TRACE
+#undef SRT_LAUNCH_TRACE1
   HIP_OK(hipGetLastError());
   HIP_OK(hipEventRecord(sl.ev1, st));
 #ifdef SRT_PHASE_TIMING

@@ -58,13 +58,16 @@ struct Common {
 // that the dipole kernel carries none of their registers or code (sharing one kernel cost it 11 %).
 // Plain `Common` means "look at fld.use_igrf at run time" (the layered kernels).
 struct CommonDipole : Common {};
-struct CommonIgrf : Common {};
+struct CommonIgrf : Common {};     // the adapters' general field tail: IGRF or dipole base, T04_s on top if use_tsy (run time)
+struct CommonIgrfOnly : Common {}; // use_igrf = 1, use_tsyganenko = 0: no T04 call sites (seven or eight per stencil) in the kernel
 template <class CM>
 __device__ __forceinline__ bool field_is_igrf(const CM &cm) {
   if constexpr (std::is_same<CM, CommonDipole>::value) return false;
-  else if constexpr (std::is_same<CM, CommonIgrf>::value) return true;
+  else if constexpr (std::is_same<CM, CommonIgrf>::value || std::is_same<CM, CommonIgrfOnly>::value) return true;
   else return cm.fld.use_igrf != 0 || cm.fld.use_tsy != 0;
 }
+template <class CM>
+constexpr bool field_igrf_only() { return std::is_same<CM, CommonIgrfOnly>::value; }
 
 // a/b for operands well inside the exponent range (every division of the hot path: frequencies, densities,
 // field magnitudes, grid spacings).  This is the compiler's own fp64 division sequence -- v_rcp_f64, two Newton
@@ -263,7 +266,7 @@ __device__ __noinline__ void t04_device(const FieldConst &f, float xg, float yg,
 // The adapters' field tail in full (interp_dens_model_adapter.f95:186,214-267): x_gsm = SM_TO_GSM_d(x); base field in
 // GSM nT as REAL -- IGRF_GSM(real(x_gsm/R_E)), or the dipole rotated to GSM; plus T04_s(real(parmod), real(psi),
 // real(x_gsm/R_E)) when use_tsyganenko; (base + tsy)*1e-9; GSM_TO_SM_d.
-template <int NP>
+template <int NP, bool IGRF_ONLY = false>
 __device__ __forceinline__ void bfield_igrf(const FieldConst &f, const double (&pt)[NP][3], double (&B)[NP][3]) {
   float xg[NP], yg[NP], zg[NP], hx[NP], hy[NP], hz[NP];
 #pragma unroll
@@ -272,7 +275,7 @@ __device__ __forceinline__ void bfield_igrf(const FieldConst &f, const double (&
     yg[i] = (float)(pt[i][1] / R_E);
     zg[i] = (float)((pt[i][2] * f.cm + pt[i][0] * f.sm) / R_E);
   }
-  if (f.use_igrf) { // wave-uniform
+  if (IGRF_ONLY || f.use_igrf) { // wave-uniform
     igrf_core<NP>(f, xg, yg, zg, hx, hy, hz);
   } else {
 #pragma unroll
@@ -289,9 +292,11 @@ __device__ __forceinline__ void bfield_igrf(const FieldConst &f, const double (&
   float tx[NP], ty[NP], tz[NP];
 #pragma unroll
   for (int i = 0; i < NP; ++i) tx[i] = ty[i] = tz[i] = 0.0f;
-  if (f.use_tsy) {
+  if constexpr (!IGRF_ONLY) {
+    if (f.use_tsy) {
 #pragma unroll
-    for (int i = 0; i < NP; ++i) t04_device(f, xg[i], yg[i], zg[i], tx[i], ty[i], tz[i]);
+      for (int i = 0; i < NP; ++i) t04_device(f, xg[i], yg[i], zg[i], tx[i], ty[i], tz[i]);
+    }
   }
 #pragma unroll
   for (int i = 0; i < NP; ++i) {

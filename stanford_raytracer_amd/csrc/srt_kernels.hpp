@@ -70,7 +70,7 @@ __device__ __forceinline__ void rhs_from_plasma(const CM &cm, const double x[3],
 #pragma unroll
       for (int i = 0; i < 7; ++i)
         for (int c = 0; c < 3; ++c) p7[i][c] = p[i][c];
-      bfield_igrf<7>(cm.fld, p7, Ball);
+      bfield_igrf<7, field_igrf_only<CM>()>(cm.fld, p7, Ball);
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) B[c] = Ball[0][c];
@@ -223,10 +223,13 @@ __device__ __forceinline__ void store_row(double *row, double t, const double x[
 
 // =============================================================================================
 // raytracer_run for a whole launch set (raytracer.f95:609-995 x the driver loop :1144-1232).
-template <class M, bool FIXED, bool USE_LDS, bool IGRF = false>
+// FOPT: field option fixed at compile time -- 0 dipole, 1 IGRF main field alone, 2 the general tail (T04_s on an IGRF or
+// dipole base, chosen at run time inside)
+template <class M, bool FIXED, bool USE_LDS, int FOPT = 0>
 __global__ __launch_bounds__(64) void trace_kernel(const M *__restrict__ mp, const Common *__restrict__ cp, TraceArgs a) {
   const M &m = *mp;
-  typedef typename std::conditional<IGRF, CommonIgrf, CommonDipole>::type CM;
+  constexpr bool IGRF = FOPT != 0;
+  typedef typename std::conditional<FOPT == 0, CommonDipole, typename std::conditional<FOPT == 1, CommonIgrfOnly, CommonIgrf>::type>::type CM;
   const CM &cm = *static_cast<const CM *>(cp);
   __shared__ __attribute__((aligned(16))) double tile[USE_LDS ? TILE_DOUBLES : 2];
   double *lds = USE_LDS ? tile : nullptr;
@@ -340,7 +343,7 @@ __global__ __launch_bounds__(64) void trace_kernel(const M *__restrict__ mp, con
     // the stencil's centre IS est2 (rhs_from_plasma below takes the fields from here)
     double Bpost[IGRF ? NPOST : 1][3];
     if constexpr (IGRF) {
-      bfield_igrf<NPOST>(cm.fld, pp, Bpost);
+      bfield_igrf<NPOST, FOPT == 1>(cm.fld, pp, Bpost);
 #pragma unroll
       for (int c = 0; c < 3; ++c) ps2.B[c] = Bpost[0][c];
     } else {
