@@ -139,6 +139,7 @@ def test_paths_agree_on_the_full_size_sample_set(tmp_path):
     x, k, w = pos[ok], kmag[ok, None] * d[ok], w[ok]
     assert len(x) >= 1000
     a = g.gradients(x, k, w, 1e-6)
+    assert np.array_equal(a, g.gradients(x, k, w, 1e-6), equal_nan=True)   # run to run: bit for bit
     b = _own_list(lambda: g.gradients(x, k, w, 1e-6))
     fin = np.isfinite(a).all(axis=1) & np.isfinite(b).all(axis=1)
     assert fin.mean() >= 0.99

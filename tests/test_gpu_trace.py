@@ -176,11 +176,15 @@ def test_interp_rays_outside_the_grid(gpu_models, oracle_models):
     assert np.max(np.abs(rows[:, 0, 16:20] - orows[:, 0, 16:20]) / orows[:, 0, 16:20]) <= 1e-11
 
 
-@pytest.mark.parametrize("name", ["ngo", "interp"])
+@pytest.mark.parametrize("name", ["ngo", "interp", "scattered"])
 def test_determinism_and_lane_independence(gpu_models, name):
-    """A ray's result must not depend on which lane/wave integrates it, nor on the refill policy."""
+    """A ray's result must not depend on which lane/wave integrates it, nor on the refill policy.  (Scattered model: the
+    staging records, the LDS-DMA record ring and the list compaction are shared by the wave -- a missed wait would show
+    up here as a run-to-run difference.)"""
     m = gpu_models[name]
     pos, d, w = wl.launch_set(3000, 91)
+    if name == "scattered":
+        pos = pos * 0.9
     kw = dict(fixedstep=0, dt0=1e-3, dtmax=0.1, maxerr=5e-4, tmax=0.05, maxsteps=40, outputper=8, del_=DELS[name])
     a = m.trace(pos, d, w, **kw)
     b = m.trace(pos, d, w, **kw)
