@@ -1,24 +1,40 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X-native many-ray Haselgrove integrator.
 
-Contract: `python bench.py --gpus N --steps K --warmup W` (N>1: launched by torch.distributed.run,
-one rank per GPU).  A "step" is one pass of the hot path over one batch of synthetic input: the whole
-launch set is traced from t=0 to its stop conditions by one kernel launch.  W untimed steps, then
-exactly K timed steps bracketed by barrier + synchronize; MAX over ranks; rank 0 prints ONE JSON line.
+Contract: `python bench.py --gpus N --steps K --warmup W` (N>1: launched by torch.distributed.run, one rank per
+GPU; --gpus must equal WORLD_SIZE).  A "step" is one pass of the hot path over one batch of synthetic input: the
+whole launch set is traced from t=0 to its stop conditions (one kernel launch per GPU), and at N>1 the kept
+trajectory rows are gathered to rank 0.  W untimed steps, then exactly K timed steps bracketed by barrier +
+synchronize; MAX over ranks; rank 0 prints ONE JSON line.
 
 Workloads (BASELINE.json configs; --workload):
-  interp256 (default)  config[2]: 1M rays, interp model on a 256^3 x 4-species ln N grid (tricubic),
-                       adaptive RK45, maxsteps=256, outputper=16 -- the configuration the north-star
-                       metric (ray-steps/s + HBM roofline) is quoted on.
-  ngo100k              config[1]: 100k rays, Ngo model, adaptive RK45, maxsteps=512, outputper=8.
-  Smaller variants for quick checks: --grid N --rays N.
-Inputs are synthetic (seeded launch set + analytic plasmasphere) and resident in HBM
-before the timed region starts.  N>1 is weak scaling: every rank traces its own launch set of the
-same size against its own model replica, then the trajectory buffers are gathered to rank 0 (RCCL).
+  interp256 (default)  config[2]: 1M rays per GPU, interp model on a 256^3 x 4-species ln N grid (tricubic),
+                       adaptive RK45, maxsteps=256, outputper=16 -- the configuration the north-star metric is
+                       quoted on.  N>1: ONE launch set of N x 1M rays (seed 3) cut into contiguous shards (weak).
+  interp4m             config[3]: 4M rays (seed 4) sharded over the N ranks, strong scaling, gather timed apart.
+  ngo100k              config[1]: 100k rays, Ngo model, adaptive RK45, maxsteps=512, outputper=8 (compute-bound).
+  scattered825k        config[4]: 1M rays, scattered model on the 825k-sample set, maxsteps=64, outputper=8.
+The default invocation additionally times one short run of the other configs (`other_configs`), so that every
+BASELINE config is driver-timed.  Inputs are synthetic (seeded launch set + analytic plasmasphere)
+and resident in HBM before the timed region starts.
+
+Multi-GPU: every step goes through stanford_raytracer_amd.parallel.trace_sharded (shard -> trace -> pack ->
+variable-length gather), the same function the gloo and 2-rank GPU tests run.
+
+Roofline (N=1): `achieved` = bytes the kernel moved through the L2's fabric side per launch (rocprofv3 PMC,
+FETCH_SIZE x2 + WRITE_SIZE, collected LIVE by two child passes of this script under rocprofv3 before this process
+touches the GPU) / the kernel's HIP-event duration in the timed region; `frac` = achieved / 8 TB/s.  The SURVEY 8d
+algorithmic figure (44 lookups x 2 KiB per accepted step) is reported beside it as `algorithmic_GBs` -- it is NOT a
+fraction of anything: the 7-point stencil shares one block, so the kernel moves far fewer bytes than that figure.
 """
 import argparse
+import csv
+import glob
+import hashlib
 import json
 import os
+import shutil
+import subprocess
 import sys
 import tempfile
 import time
@@ -28,24 +44,28 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ALGO_BYTES_PER_STEP = {  # algorithmic bytes per ACCEPTED ray-step
-    # 44 distinct lookups x (8 corners x 8 arrays x 4 species x 8 B) + state r/w 160 B + row 256 B/outputper
-    "interp": lambda outputper: 44 * 2048 + 160 + 256.0 / outputper,
-    # no table: state r/w + emitted row only
-    "ngo": lambda outputper: 160 + 256.0 / outputper,
-    # scattered: data-dependent (visited samples x 64 B per lookup); reported from the neighbour statistics
-    "scattered": lambda outputper: 160 + 256.0 / outputper,
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
+FP64_VALU_PEAK_TFLOPS = 78.6  # MI355X_MICROARCH.md: fp64 vector peak
+# MI355X_MICROARCH.md, "Indexed rows: gather into LDS": what a gather of a 151 MB table into LDS reaches chip-wide
+# (the resident rays' coefficient blocks are ~128 MiB and are served largely by the Infinity Cache)
+LDS_GATHER_CEILING_GBS = (7400.0, 7900.0)
+ALGO_INTERP = lambda outputper: 44 * 2048 + 160 + 256.0 / outputper  # SURVEY.md 8(d), bytes per ACCEPTED step
+
+WORKLOADS = {
+    "interp256": dict(kind="interp", rays=1_000_000, seed=3, scaling="weak", maxsteps=256, outputper=16, del_=1e-6),
+    "interp4m": dict(kind="interp", rays=4_000_000, seed=4, scaling="strong", maxsteps=256, outputper=16, del_=1e-6),
+    "ngo100k": dict(kind="ngo", rays=100_000, seed=2, scaling="weak", maxsteps=512, outputper=8, del_=1e-4),
+    "scattered825k": dict(kind="scattered", rays=1_000_000, seed=5, scaling="weak", maxsteps=64, outputper=8, del_=1e-6),
 }
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="interp256", choices=["interp256", "ngo100k", "scattered825k"])
-    ap.add_argument("--rays", type=int, default=0, help="override rays per GPU")
+    ap.add_argument("--workload", default="interp256", choices=sorted(WORKLOADS))
+    ap.add_argument("--rays", type=int, default=0, help="override rays (per GPU for weak workloads, total for interp4m)")
     ap.add_argument("--grid", type=int, default=0, help="override grid nodes per axis (interp)")
     ap.add_argument("--maxsteps", type=int, default=0)
     ap.add_argument("--points", type=int, default=0, help="override sample count (scattered)")
@@ -53,28 +73,316 @@ def parse_args():
     ap.add_argument("--use-igrf", type=int, default=0, choices=[0, 1], help="IGRF main field instead of the dipole (driver flag --use_igrf)")
     ap.add_argument("--use-tsyganenko", type=int, default=0, choices=[0, 1],
                     help="add the T04_s external field (driver flag --use_tsyganenko; PARMOD = Pdyn 4, Dst -30, By 1, Bz -5, W .1-.3)")
-    ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--no-gather", action="store_true", help="N>1: trace only (no pack, no gather)")
     ap.add_argument("--damping-rays", type=int, default=100_000,
                     help="rays whose kept rows get the damping post-pass after the timed region (N=1 only; 0 = skip)")
     ap.add_argument("--refill", type=int, default=0)
-    ap.add_argument("--streams", type=int, default=2, help="HIP streams the steps alternate on (1 = strictly serial)")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="HIP streams the steps alternate on at N=1 (1 = strictly serial, the default: kernel time == step "
+                         "time; 2 lets the drain of one launch overlap the ramp-up of the next, +5 %%)")
     ap.add_argument("--ray-order", type=int, default=1, choices=[0, 1],
                     help="srt_params.ray_order: 1 = the library works through the launch set sorted by launch cell "
                          "(device sort inside the timed region; SURVEY 8d allows this permutation), 0 = as given")
-    return ap.parse_args()
+    ap.add_argument("--traffic", default="auto", choices=["auto", "live", "file", "off"],
+                    help="where roofline.traffic comes from: live = two rocprofv3 PMC child passes of this script "
+                         "(FETCH_SIZE, WRITE_SIZE) before the timed run; file = profiles/traffic_<workload>.json if it was "
+                         "collected for these kernel sources; auto = live at N=1 when rocprofv3 exists, else file")
+    ap.add_argument("--other-configs", type=int, default=-1, choices=[-1, 0, 1],
+                    help="time one short run of the other BASELINE configs as well (-1 = only in the default invocation)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # internal: one bare launch under rocprofv3
+    return ap.parse_args(argv)
 
 
+# --------------------------------------------------------------------------------------------- provenance
+def kernel_source_hash():
+    """sha256 over the sources the kernels are compiled from: a traffic profile belongs to exactly one such hash."""
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "stanford_raytracer_amd", "csrc", "*"))) + [os.path.join(ROOT, "include", "srt.h")]
+    for f in files:
+        if os.path.isfile(f):
+            h.update(os.path.basename(f).encode())
+            h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+# --------------------------------------------------------------------------------------------- PMC child passes
+def pmc_pass(counters, child_args, timeout=420):
+    """One rocprofv3 --pmc pass over `python3 bench.py --pmc-child <child_args>`: {counter: sum over trace_kernel
+    dispatches}, plus "_dispatches".  Runs as a child process; call before this process initialises the GPU."""
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not found"
+    out = tempfile.mkdtemp(prefix="srt_pmc_", dir="/tmp")
+    cmd = [exe, "--pmc"] + list(counters) + ["--kernel-trace", "--output-format", "csv", "-d", out, "--",
+                                              sys.executable, os.path.abspath(__file__), "--pmc-child"] + child_args
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    try:
+        r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout)
+    except subprocess.TimeoutExpired:
+        shutil.rmtree(out, ignore_errors=True)
+        return None, "rocprofv3 pass timed out after %d s" % timeout
+    vals, ndisp = {}, set()
+    for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if "trace_kernel" in row["Kernel_Name"]:
+                vals[row["Counter_Name"]] = vals.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+                ndisp.add(row["Dispatch_Id"])
+    shutil.rmtree(out, ignore_errors=True)
+    if r.returncode != 0 or not vals:
+        return None, "rocprofv3 pass failed (rc %d): %s" % (r.returncode, r.stdout.decode(errors="replace")[-300:])
+    vals["_dispatches"] = len(ndisp)
+    for line in r.stdout.decode(errors="replace").splitlines():
+        if line.startswith('{"pmc_child"'):
+            vals["_child"] = json.loads(line)["pmc_child"]
+    return vals, None
+
+
+def child_args_for(args, workload, rays=0):
+    a = ["--workload", workload, "--steps", "1", "--warmup", "0", "--ray-order", str(args.ray_order)]
+    if rays or args.rays:
+        a += ["--rays", str(rays or args.rays)]
+    for k, v in (("--grid", args.grid), ("--maxsteps", args.maxsteps), ("--points", args.points), ("--refill", args.refill)):
+        if v:
+            a += [k, str(v)]
+    if args.use_igrf:
+        a += ["--use-igrf", "1"]
+    if args.use_tsyganenko:
+        a += ["--use-tsyganenko", "1"]
+    return a
+
+
+def live_traffic(args, workload, rays=0):
+    """FETCH_SIZE and WRITE_SIZE in SEPARATE passes (they do not fit one pass on gfx950) with the corrections of
+    MI355X_MICROARCH.md (HBM section): both are KiB; FETCH_SIZE tallies 128-B requests at 64 B -> x2; WRITE_SIZE as read."""
+    ca = child_args_for(args, workload, rays)
+    f, err = pmc_pass(["FETCH_SIZE"], ca)
+    if f is None:
+        return None, err
+    w, err = pmc_pass(["WRITE_SIZE"], ca)
+    if w is None:
+        return None, err
+    if f["_dispatches"] != 1 or w["_dispatches"] != 1:
+        return None, "expected one trace_kernel dispatch per pass, saw %d / %d" % (f["_dispatches"], w["_dispatches"])
+    return {"FETCH_SIZE_KB": f["FETCH_SIZE"], "WRITE_SIZE_KB": w["WRITE_SIZE"],
+            "bytes_per_launch": f["FETCH_SIZE"] * 1024.0 * 2.0 + w["WRITE_SIZE"] * 1024.0,
+            "accepted_steps_of_counted_launch": (f.get("_child") or {}).get("accepted"),
+            "source": "live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes of this run"}, None
+
+
+def file_traffic(workload, rays, grid_n, khash):
+    """profiles/traffic_<workload>.json, only if it was collected for exactly these kernel sources and this size."""
+    path = os.path.join(ROOT, "profiles", "traffic_%s.json" % workload)
+    if not os.path.exists(path):
+        return None, "no %s" % os.path.relpath(path, ROOT)
+    try:
+        tj = json.load(open(path))
+    except Exception as e:
+        return None, "unreadable %s: %s" % (path, e)
+    if tj.get("kernel_source_sha16") != khash:
+        return None, "STALE: %s was collected for kernel sources %s, this build is %s" % (
+            os.path.relpath(path, ROOT), tj.get("kernel_source_sha16"), khash)
+    if tj.get("rays") != rays or tj.get("grid", 0) != grid_n:
+        return None, "%s is for %s rays / grid %s" % (os.path.relpath(path, ROOT), tj.get("rays"), tj.get("grid"))
+    return {"FETCH_SIZE_KB": tj["FETCH_SIZE_KB"], "WRITE_SIZE_KB": tj["WRITE_SIZE_KB"],
+            "bytes_per_launch": tj["hbm_bytes_per_launch"], "accepted_steps_of_counted_launch": tj.get("accepted_steps_per_launch"),
+            "source": "file: %s (same kernel sources %s)" % (os.path.relpath(path, ROOT), khash)}, None
+
+
+# --------------------------------------------------------------------------------------------- workloads
+class Ctx:
+    """Per-process state shared by the workloads of one bench run (device, ranks, cached models)."""
+
+    def __init__(self, args, torch, dev, dist, rank, world):
+        self.args, self.torch, self.dev, self.dist, self.rank, self.world = args, torch, dev, dist, rank, world
+        self.models = {}
+        self.tmp = tempfile.mkdtemp(prefix="srt_bench_")
+
+
+def make_model(ctx, kind, grid_n, npts):
+    from stanford_raytracer_amd import api, workloads as wl
+
+    key = (kind, grid_n, npts)
+    if key in ctx.models:
+        return ctx.models[key] + (0.0,)
+    t0 = time.time()
+    extra = {}
+    if kind == "interp":
+        F, bounds = wl.make_grid(grid_n, half_width=10.0 * wl.R_E)
+        model = api.Model.interp(F, bounds, wl.QS, wl.MS)
+        del F
+    elif kind == "scattered":
+        if npts == 825_000:  # SURVEY 8(d) config 5: 200 k uniform + 600 k importance-sampled + 25 k shell
+            pts, lnN = wl.make_points_config5(5)
+        else:
+            pts, lnN = wl.make_points(int(npts * 0.97), npts - int(npts * 0.97), 5, half_width=10.0 * wl.R_E)
+        pfile = os.path.join(ctx.tmp, "points_%d.bin" % npts)
+        api.write_points_file(pfile, np.concatenate([pts, lnN], axis=1), np.array([-10.0 * wl.R_E, 10.0 * wl.R_E] * 3),
+                              wl.QS, wl.MS, binary=True)
+        model = api.Model.scattered_file(pfile, window_scale=1.5, order=2, exact=0, local_window_scale=5.0)
+        extra["points_file"] = pfile
+    else:
+        cfg = os.path.join(ctx.tmp, "newray.in")
+        with open(cfg, "w") as f:
+            f.write(wl.NEWRAY_PLASMAPAUSE)
+        model = api.Model.ngo(cfg)
+    a = ctx.args
+    if a.use_igrf or a.use_tsyganenko:
+        model.set_field(use_igrf=a.use_igrf, use_tsyganenko=a.use_tsyganenko,
+                        parmod=[4.0, -30.0, 1.0, -5.0, 0.132, 0.303, 0.083, 0.07, 0.211, 0.308])
+    ctx.models[key] = (model, extra)
+    return model, extra, time.time() - t0
+
+
+def run_workload(ctx, name, steps, warmup, rays_override=0, nstream=1, keep=False):
+    """W untimed + K timed steps of one workload on this rank's shard.  Returns a dict (all ranks; whole-job numbers
+    are reduced over ranks) -- or, with keep=True, also the DeviceBatch so the caller can post-process its rows."""
+    from stanford_raytracer_amd import api, parallel, workloads as wl
+    from stanford_raytracer_amd.device_batch import DeviceBatch
+
+    args, torch, dev, dist, rank, world = ctx.args, ctx.torch, ctx.dev, ctx.dist, ctx.rank, ctx.world
+    W = WORKLOADS[name]
+    kind = W["kind"]
+    grid_n = (args.grid or 256) if kind == "interp" else 0
+    npts = (args.points or 825_000) if kind == "scattered" else 0
+    per_gpu = rays_override or W["rays"]
+    total = per_gpu * world if W["scaling"] == "weak" else per_gpu
+    p = api.make_params(fixedstep=0, dt0=1e-3, dtmax=0.1, maxerr=5e-4, tmax=0.5, root=2, minalt=wl.MINALT,
+                        maxsteps=args.maxsteps or W["maxsteps"], outputper=W["outputper"], del_=W["del_"],
+                        refill_threshold=args.refill, ray_order=args.ray_order)
+    model, extra, setup_s = make_model(ctx, kind, grid_n, npts)
+    # ONE launch set for the whole job, cut into contiguous shards (ceil(n/world) rays per rank)
+    pos0, dir0, w0 = wl.launch_set(total, W["seed"])
+    lo, hi = parallel.shard_bounds(total, rank, world)
+    nstream = max(1, nstream) if world == 1 else 1
+    batch = DeviceBatch(model, p, pos0[lo:hi], dir0[lo:hi], w0[lo:hi], dev, nbuf=nstream)
+    streams = [torch.cuda.Stream(dev) for _ in range(nstream)] if nstream > 1 else [torch.cuda.current_stream(dev)]
+    gather = world > 1 and not args.no_gather
+    pack = lambda rows, nrows: parallel.pack_rows_device(rows, nrows, p.outputper)
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    def one_step(i, cnt, tm):
+        if gather:  # shard -> trace -> pack -> variable-length gather to rank 0: the tested multi-GPU path
+            batch.out[0]["cnt"] = cnt
+            parallel.trace_sharded(dist, total, lambda a, b: batch.trace(0), pack, dst=0, timings=tm)
+        else:
+            with torch.cuda.stream(streams[i % nstream]):
+                batch.launch(i % nstream, streams[i % nstream], counters=cnt)
+
+    torch.cuda.synchronize(dev)  # inputs are resident before anything is launched
+    for i in range(warmup):
+        one_step(i, torch.zeros(4, dtype=torch.int64, device=dev), {})
+    sync_all()
+    cnts = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(steps)]
+    tms = [dict() for _ in range(steps)]
+    kernel_ms = [None] * steps
+    LAG = 2  # a launch's duration is read two launches later (the library keeps the events of the last 4 launches)
+    t_start = time.perf_counter()
+    for i in range(steps):
+        one_step(i, cnts[i], tms[i])
+        if gather:
+            kernel_ms[i] = model.launch_ms(0) if hi > lo else 0.0  # trace_sharded has synchronised
+        elif i >= LAG:
+            kernel_ms[i - LAG] = model.launch_ms(LAG)
+    sync_all()
+    elapsed = time.perf_counter() - t_start
+    if not gather:
+        for i in range(max(0, steps - LAG), steps):
+            kernel_ms[i] = model.launch_ms(steps - 1 - i)
+    c = np.sum([x.cpu().numpy() for x in cnts], axis=0) if steps else np.zeros(4, dtype=np.int64)
+    red = np.array([elapsed, float(np.mean(kernel_ms)) if steps else 0.0,
+                    float(np.mean([t.get("gather_s", 0.0) for t in tms])) if steps else 0.0,
+                    float(np.mean([t.get("pack_s", 0.0) for t in tms])) if steps else 0.0])
+    tot = np.array([int(c[1]), int(c[2]), int(c[3])], dtype=np.int64)
+    if dist is not None:
+        t = torch.tensor(red, dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        s = torch.tensor(tot, dtype=torch.int64, device=dev)
+        dist.all_reduce(s, op=dist.ReduceOp.SUM)
+        red, tot = t.cpu().numpy(), s.cpu().numpy()
+    o = batch.out[0]
+    res = {
+        "workload": name, "kind": kind, "grid": grid_n, "points": npts, "params": p, "model": model, "extra": extra,
+        "total_rays": total, "rays_this_rank": hi - lo, "scaling": W["scaling"], "steps": steps, "warmup": warmup,
+        "elapsed_s": float(red[0]), "ms_per_step": 1e3 * float(red[0]) / max(steps, 1),
+        "kernel_ms": float(red[1]), "kernel_ms_rank0": float(np.mean(kernel_ms)) if steps else 0.0,
+        "gather_ms": 1e3 * float(red[2]) if gather else None, "pack_ms": 1e3 * float(red[3]) if gather else None,
+        "gather_bytes": int(np.mean([t.get("gather_bytes", 0) for t in tms])) if (gather and steps) else None,
+        "accepted": int(tot[0]), "attempts": int(tot[1]), "wave_attempts": int(tot[2]),
+        "value": float(tot[0]) / max(float(red[0]), 1e-12), "setup_s": setup_s, "nstream": nstream, "gather": gather,
+        "stop": o["stop"].cpu().numpy(), "nrows": o["nrows"].cpu().numpy(),
+        "launch": (pos0[lo:hi], dir0[lo:hi], w0[lo:hi]),
+    }
+    if keep:
+        res["batch"] = batch
+    return res
+
+
+def describe(res):
+    """config.workload text."""
+    p, kind = res["params"], res["kind"]
+    what = {"interp": "interp_dens_model on %d^3 x4 lnN grid (tricubic)" % res["grid"],
+            "ngo": "ngo_dens_model", "scattered": "scattered_interp_dens_model (%d samples, order 2, window 1.5/5)" % res["points"]}[kind]
+    return "%s: %d rays (%s scaling), %s, dipole B, adaptive RK45, maxsteps %d, outputper %d" % (
+        res["workload"], res["total_rays"], res["scaling"], what, p.maxsteps, p.outputper)
+
+
+def detail_of(res):
+    steps = max(res["steps"], 1)
+    return {"accepted_steps_per_launch_all_ranks": res["accepted"] / steps,
+            "attempts_per_launch": res["attempts"] / steps,
+            "reject_ratio": 1.0 - res["accepted"] / max(res["attempts"], 1),
+            "lane_occupancy": res["attempts"] / max(64 * res["wave_attempts"], 1),
+            "mean_rows_per_ray_rank0": float(res["nrows"].mean()) if len(res["nrows"]) else 0.0,
+            "stopcond_hist_rank0": {str(int(k)): int(v) for k, v in zip(*np.unique(res["stop"], return_counts=True))},
+            "model_setup_s": res["setup_s"], "model_device_GB": res["model"].device_bytes / 1e9}
+
+
+# --------------------------------------------------------------------------------------------- main
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE is %d: for N > 1 launch with `python -m torch.distributed.run "
+                         "--nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N ...` (one rank per GPU)\n"
+                         % (args.gpus, world))
+        sys.exit(2)
+    default_invocation = (args.workload == "interp256" and not (args.rays or args.grid or args.maxsteps or args.use_igrf
+                                                                or args.use_tsyganenko))
+    want_other = args.other_configs == 1 or (args.other_configs == -1 and default_invocation and not args.pmc_child)
+    khash = kernel_source_hash()
+
+    # ---- 0. counter passes: child processes under rocprofv3, BEFORE this process touches the GPU -------------------
+    traffic, traffic_note, other_pmc = None, None, {}
+    mode = args.traffic
+    if args.pmc_child or world > 1:
+        mode = "off" if args.pmc_child else ("file" if mode in ("auto", "live") else mode)
+    elif mode == "auto":
+        mode = "live" if shutil.which("rocprofv3") else "file"
+    if mode == "live":
+        traffic, traffic_note = live_traffic(args, args.workload)
+        if want_other:  # config[1]: fp64 VALU mix of one launch; config[4]: fabric bytes of a 100k-ray launch
+            v, err = pmc_pass(["SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_TRANS_F64",
+                               "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES"],
+                              child_args_for(args, "ngo100k"))
+            other_pmc["ngo100k"] = v if v is not None else {"error": err}
+            t, err = live_traffic(args, "scattered825k", rays=100_000)
+            other_pmc["scattered825k"] = t if t is not None else {"error": err}
+
     import torch
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    # one rank per GPU.  (Rehearsal on a 1-GPU box: SRT_BENCH_BACKEND=gloo --no-gather folds the ranks onto the
-    # devices that exist; RCCL itself refuses two ranks on one device.)
+    # one rank per GPU.  (Rehearsal on a 1-GPU box: SRT_BENCH_BACKEND=gloo folds the ranks onto the devices that exist;
+    # RCCL itself refuses two ranks on one device.)
     backend = os.environ.get("SRT_BENCH_BACKEND", "nccl")
     if backend != "nccl":
         local_rank = local_rank % torch.cuda.device_count()
@@ -94,128 +402,25 @@ def main():
     from stanford_raytracer_amd import api, workloads as wl
 
     api.init(local_rank)
+    ctx = Ctx(args, torch, dev, dist, rank, world)
 
-    # ---------------------------------------------------------------- workload
-    if args.workload == "interp256":
-        kind = "interp"
-        nrays = args.rays or 1_000_000
-        grid_n = args.grid or 256
-        seed = 3
-        p = api.make_params(fixedstep=0, dt0=1e-3, dtmax=0.1, maxerr=5e-4, tmax=0.5, root=2, minalt=wl.MINALT,
-                            maxsteps=args.maxsteps or 256, outputper=16, del_=1e-6, refill_threshold=args.refill)
-        t0 = time.time()
-        F, bounds = wl.make_grid(grid_n, half_width=10.0 * wl.R_E)
-        model = api.Model.interp(F, bounds, wl.QS, wl.MS)
-        del F
-        setup_s = time.time() - t0
-        wname = "%d rays/GPU, interp_dens_model on %d^3 x4 lnN grid (tricubic), dipole B, adaptive RK45" % (nrays, grid_n)
-    elif args.workload == "scattered825k":
-        kind = "scattered"
-        nrays = args.rays or 1_000_000
-        grid_n = 0
-        seed = 5
-        p = api.make_params(fixedstep=0, dt0=1e-3, dtmax=0.1, maxerr=5e-4, tmax=0.5, root=2, minalt=wl.MINALT,
-                            maxsteps=args.maxsteps or 64, outputper=8, del_=1e-6, refill_threshold=args.refill)
-        t0 = time.time()
-        npts = args.points or 825_000
-        if npts == 825_000:  # 200 k uniform + 600 k importance-sampled + 25 k shell
-            pts, lnN = wl.make_points_config5(5)
+    res = run_workload(ctx, args.workload, args.steps, args.warmup, rays_override=args.rays, nstream=args.streams, keep=True)
+    if args.pmc_child:  # the parent (pmc_pass) reads this line from the child's stdout
+        print(json.dumps({"pmc_child": {"accepted": res["accepted"], "kernel_ms": res["kernel_ms_rank0"], "rays": res["rays_this_rank"]}}))
+        return
+    if mode == "file":
+        traffic, traffic_note = file_traffic(args.workload, res["rays_this_rank"], res["grid"], khash)
+    if traffic is None and traffic_note and rank == 0:
+        sys.stderr.write("bench.py: roofline.traffic unavailable -- %s\n" % traffic_note)
+
+    # ---- the other BASELINE configs, one short timed run each (outside the headline's timed region) ----------------
+    other = {}
+    if want_other:
+        if world == 1:
+            for name, st, wu in (("ngo100k", 3, 1), ("scattered825k", 1, 0), ("interp4m", 1, 1)):
+                other[name] = other_config_line(ctx, run_workload(ctx, name, st, wu), other_pmc.get(name))
         else:
-            pts, lnN = wl.make_points(int(npts * 0.97), npts - int(npts * 0.97), 5, half_width=10.0 * wl.R_E)
-        pfile = os.path.join(tempfile.mkdtemp(), "points.txt")
-        wl.write_points_file(pfile, pts, lnN, np.array([-10.0 * wl.R_E, 10.0 * wl.R_E] * 3))
-        model = api.Model.scattered_file(pfile, window_scale=1.5, order=2, exact=0, local_window_scale=5.0)
-        args.points_file = pfile
-        setup_s = time.time() - t0
-        wname = "%d rays/GPU, scattered_interp_dens_model (%d samples, order 2, window 1.5/5), dipole B, adaptive RK45" % (nrays, npts)
-    else:
-        kind = "ngo"
-        nrays = args.rays or 100_000
-        grid_n = 0
-        seed = 2
-        p = api.make_params(fixedstep=0, dt0=1e-3, dtmax=0.1, maxerr=5e-4, tmax=0.5, root=2, minalt=wl.MINALT,
-                            maxsteps=args.maxsteps or 512, outputper=8, del_=1e-4, refill_threshold=args.refill)
-        t0 = time.time()
-        cfg = os.path.join(tempfile.mkdtemp(), "newray.in")
-        with open(cfg, "w") as f:
-            f.write(wl.NEWRAY_PLASMAPAUSE)
-        model = api.Model.ngo(cfg)
-        setup_s = time.time() - t0
-        wname = "%d rays/GPU, ngo_dens_model, dipole B, adaptive RK45" % nrays
-
-    if args.use_igrf or args.use_tsyganenko:
-        model.set_field(use_igrf=args.use_igrf, use_tsyganenko=args.use_tsyganenko,
-                        parmod=[4.0, -30.0, 1.0, -5.0, 0.132, 0.303, 0.083, 0.07, 0.211, 0.308])
-        wname += (", IGRF main field" if args.use_igrf else "") + (", T04_s external field" if args.use_tsyganenko else "")
-    pos0, dir0, w0 = wl.launch_set(nrays, seed + 1000 * rank)
-    p.ray_order = args.ray_order
-    slots = api.lib().srt_rows_per_ray(p)
-    d_pos = torch.from_numpy(np.ascontiguousarray(pos0.T)).to(dev)  # SoA [3][n]
-    d_dir = torch.from_numpy(np.ascontiguousarray(dir0.T)).to(dev)
-    d_w = torch.from_numpy(w0).to(dev)
-    # Steps are issued alternately on `--streams` HIP streams (default 2), each with its own output buffers: the
-    # drain of one launch (queue empty, waves thinning out) overlaps the ramp-up of the next, and on N > 1 the RCCL
-    # gather of step k overlaps the kernel of step k+1.  All K steps complete inside the timed region.
-    nstream = max(1, args.streams)
-    streams = [torch.cuda.Stream(dev) for _ in range(nstream)] if nstream > 1 else [torch.cuda.current_stream(dev)]
-    outs = [{"rows": torch.zeros((nrays, slots, api.ROW), dtype=torch.float64, device=dev),
-             "nrows": torch.zeros(nrays, dtype=torch.int32, device=dev),
-             "stop": torch.zeros(nrays, dtype=torch.int32, device=dev)} for _ in range(nstream)]
-    d_rows, d_nrows, d_stop = outs[0]["rows"], outs[0]["nrows"], outs[0]["stop"]
-    gather_buf = None
-    if dist is not None and not args.no_gather and rank == 0:
-        gather_buf = [torch.empty_like(d_rows) for _ in range(world)]
-
-    import ctypes as C
-
-    def one_step(i, cnt):
-        st, o = streams[i % nstream], outs[i % nstream]
-        with torch.cuda.stream(st):
-            rc = api.lib().srt_trace_batch_device(model.h, C.byref(p), nrays, d_pos.data_ptr(), d_dir.data_ptr(),
-                                                  d_w.data_ptr(), o["rows"].data_ptr(), o["nrows"].data_ptr(),
-                                                  o["stop"].data_ptr(), cnt.data_ptr(), st.cuda_stream)
-            if rc != 0:
-                raise RuntimeError(api.lib().srt_last_error().decode())
-            if dist is not None and not args.no_gather:
-                dist.gather(o["rows"], gather_buf, dst=0)
-
-    def sync_all():
-        torch.cuda.synchronize(dev)
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    torch.cuda.synchronize(dev)  # inputs are resident before anything is launched on the side streams
-    wcnt = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(args.warmup)]
-    for i in range(args.warmup):
-        one_step(i, wcnt[i])
-    sync_all()
-    cnts = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(args.steps)]
-    kernel_ms = [None] * args.steps
-    LAG = 2  # a launch's duration is read two launches later (the library keeps the events of the last 4 launches)
-    t_start = time.perf_counter()
-    for i in range(args.steps):
-        one_step(i, cnts[i])
-        if i >= LAG:
-            kernel_ms[i - LAG] = model.launch_ms(LAG)
-    sync_all()
-    elapsed = time.perf_counter() - t_start
-    for i in range(max(0, args.steps - LAG), args.steps):
-        kernel_ms[i] = model.launch_ms(args.steps - 1 - i)
-    steps_acc = attempts = wave_attempts = 0
-    for c in cnts:
-        c = c.cpu().numpy()
-        steps_acc += int(c[1])
-        attempts += int(c[2])
-        wave_attempts += int(c[3])
-
-    tot_steps, tmax = steps_acc, elapsed
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        s = torch.tensor([steps_acc], dtype=torch.int64, device=dev)
-        dist.all_reduce(s, op=dist.ReduceOp.SUM)
-        tmax, tot_steps = float(t.item()), int(s.item())
+            other["interp4m"] = other_config_line(ctx, run_workload(ctx, "interp4m", 2, 1), None)
 
     stream_gbs = None
     if rank == 0 and world == 1:
@@ -236,67 +441,157 @@ def main():
             del src, dst
         except Exception:
             stream_gbs = None
+
     if rank == 0:
-        stop = d_stop.cpu().numpy()
-        nrows = d_nrows.cpu().numpy()
-        steps_per_launch = steps_acc / max(args.steps, 1)
-        k_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
-        algo = ALGO_BYTES_PER_STEP[kind](p.outputper) * steps_per_launch
-        achieved = algo / (k_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                if tj.get("rays") == nrays and tj.get("grid", 0) == grid_n:
-                    traffic = tj["hbm_bytes_per_launch"]
-            except Exception:
-                traffic = None
+        p, kind = res["params"], res["kind"]
+        k_ms = res["kernel_ms_rank0"]
+        steps_rank0 = float(res["nrows"].astype(np.int64).clip(1).sum() - len(res["nrows"]))  # accepted steps of THIS rank's launch
         out = {
             "metric": "ray-steps/sec (whole node) + achieved HBM GB/s vs roofline",
-            "value": tot_steps / tmax,
+            "value": res["value"],
             "unit": "accepted ray-steps/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": 1e3 * tmax / max(args.steps, 1),
+            "ms_per_step": res["ms_per_step"],
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": res["scaling"],
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": wname, "rays_per_gpu": nrays, "grid": grid_n, "maxsteps": p.maxsteps,
-                       "outputper": p.outputper, "integrator": "rkf45 adaptive", "parallelism": "rays sharded x%d" % world,
+            "config": {"workload": describe(res), "total_rays": res["total_rays"], "rays_per_gpu": res["rays_this_rank"],
+                       "grid": res["grid"], "maxsteps": p.maxsteps, "outputper": p.outputper, "integrator": "rkf45 adaptive",
+                       "parallelism": "one launch set, contiguous shards x%d (parallel.trace_sharded)" % world if world > 1 else "1 GPU",
                        "ray_order": "launch-cell Morton order, sorted on the device inside the timed region" if (args.ray_order and kind == "interp") else "as given",
-                       "gather": bool(dist is not None and not args.no_gather), "streams": nstream},
-            # achieved/frac: ALGORITHMIC bytes (every lookup counted at 2 KiB) / kernel time -- exceeds the
-            # HBM peak because consecutive lookups of a ray re-read the same block.  traffic: fabric-side bytes per
-            # launch from the PMC passes (profiles/traffic_*.json); traffic_GBs = traffic / kernel time is the physical
-            # rate to hold against the 8 TB/s peak (traffic_frac).
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_GBs": (traffic / (k_ms * 1e-3) / 1e9) if traffic else None,
-                         "traffic_frac": (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                         "stream_copy_GBs": stream_gbs,
-                         "kernel": "trace_kernel<%s,adaptive>" % kind, "kernel_ms": k_ms,
-                         "algorithmic_bytes_per_accepted_step": ALGO_BYTES_PER_STEP[kind](p.outputper),
-                         "accepted_steps_per_launch": steps_per_launch},
-            "detail": {"attempts_per_launch": attempts / max(args.steps, 1),
-                       "reject_ratio": 1.0 - steps_acc / max(attempts, 1),
-                       "lane_occupancy": attempts / max(64 * wave_attempts, 1),
-                       "mean_rows_per_ray": float(nrows.mean()),
-                       "stopcond_hist": {str(int(k)): int(v) for k, v in zip(*np.unique(stop, return_counts=True))},
-                       "model_setup_s": setup_s, "model_device_GB": model.device_bytes / 1e9},
+                       "gather": res["gather"], "streams": res["nstream"]},
+            "roofline": roofline_of(res, k_ms, steps_rank0, traffic, traffic_note, stream_gbs, khash),
+            "detail": detail_of(res),
         }
+        if world > 1:
+            out["multi_gpu"] = {"gather_ms": res["gather_ms"], "pack_ms": res["pack_ms"], "kernel_ms_max_over_ranks": res["kernel_ms"],
+                                "gather_bytes_into_rank0": res["gather_bytes"],
+                                "gather_GBs": (res["gather_bytes"] / (res["gather_ms"] * 1e-3) / 1e9) if res["gather_ms"] else None,
+                                "note": "per step, max over ranks: trace (kernel_ms) + pack + variable-length gather of the kept rows "
+                                        "(all_gather of counts, grouped send/recv of the packed rows, nrows and stop codes to rank 0)"}
+        if other:
+            out["other_configs"] = other
         if args.damping_rays > 0 and world == 1:
-            out["detail"]["damping"] = damping_leg(args, api, model, p, slots, d_rows, d_nrows, d_w, dev, torch, nrows)
-        out["cpu_baseline"] = cpu_baseline(args, kind, p, wl, pos0, dir0, w0, grid_n) if (args.cpu_seconds > 0 and world == 1) else None
-        # the real reference (Fortran, one core -- its only mode), when its prebuilt harness travelled with the repo
-        out["cpu_reference"] = cpu_reference(args, kind, p, wl, pos0, dir0, w0) if (args.cpu_seconds > 0 and world == 1) else None
+            b = res["batch"]
+            out["detail"]["damping"] = damping_leg(args, api, res["model"], p, b.slots, b.out[0]["rows"], b.out[0]["nrows"], b.d_w, dev, torch, res["nrows"])
+        if args.cpu_seconds > 0 and world == 1:
+            pos0, dir0, w0 = res["launch"]
+            out["cpu_baseline"] = cpu_baseline(args, kind, p, wl, pos0, dir0, w0, res["grid"], res["extra"])
+            # the real reference (Fortran, one core -- its only mode), when its prebuilt harness travelled with the repo
+            out["cpu_reference"] = cpu_reference(args, kind, p, wl, pos0, dir0, w0)
+        else:
+            out["cpu_baseline"] = None
         print(json.dumps(out))
+        if traffic is not None and traffic["source"].startswith("live"):
+            save_traffic(args.workload, res, traffic, khash, k_ms)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def roofline_of(res, k_ms, steps_per_launch, traffic, traffic_note, stream_gbs, khash):
+    kind, p = res["kind"], res["params"]
+    r = {"kernel": "trace_kernel<%s,adaptive>" % kind, "kernel_ms": k_ms, "accepted_steps_per_launch": steps_per_launch,
+         "kernel_source_sha16": khash}
+    if kind == "ngo":  # no table: compute-bound; the fp64 mix comes from the PMC pass (other_configs carries it in the default run)
+        r.update({"bound": "fp64_valu", "achieved": None, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None})
+        return r
+    tb = traffic["bytes_per_launch"] if traffic else None
+    if traffic and traffic.get("accepted_steps_of_counted_launch") not in (None, steps_per_launch):
+        r["traffic_warning"] = "the counted launch had %s accepted steps, this run's launches %s" % (
+            traffic["accepted_steps_of_counted_launch"], steps_per_launch)
+    achieved = (tb / (k_ms * 1e-3) / 1e9) if (tb and k_ms > 0) else None
+    r.update({
+        "bound": "hbm",
+        # achieved = MEASURED bytes through the L2's fabric side per launch / kernel time (NOT the algorithmic figure)
+        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
+        "traffic": tb, "traffic_source": traffic["source"] if traffic else ("unavailable: %s" % traffic_note),
+        "traffic_bytes_per_accepted_step": (tb / steps_per_launch) if (tb and steps_per_launch) else None,
+        "traffic_side": "L2 fabric side (TCC->EA requests): Infinity-Cache hits are included; rocprofv3 on gfx950 lists no "
+                        "DRAM-side (memory-controller) counter, so DRAM bytes cannot be separated",
+        "stream_copy_GBs": stream_gbs,
+        "frac_of_stream_copy": (achieved / stream_gbs) if (achieved and stream_gbs) else None,
+        "lds_gather_ceiling_GBs": list(LDS_GATHER_CEILING_GBS),
+        "frac_of_lds_gather_ceiling": (achieved / LDS_GATHER_CEILING_GBS[1]) if achieved else None,
+    })
+    if kind == "interp":
+        ab = ALGO_INTERP(p.outputper)
+        r.update({"algorithmic_bytes_per_accepted_step": ab,
+                  "algorithmic_GBs": (ab * steps_per_launch / (k_ms * 1e-3) / 1e9) if k_ms > 0 else None,
+                  "algorithmic_note": "SURVEY 8d figure (44 lookups x 2 KiB + state + row): counts every stencil point as its own "
+                                      "2-KiB read; the kernel stages 6 blocks per attempt, so this rate exceeds the peak and is not a fraction"})
+    return r
+
+
+def other_config_line(ctx, res, pmc):
+    """One BASELINE config timed beside the headline: value, step time, kernel time and the roofline that bounds it."""
+    k_ms = res["kernel_ms_rank0"]
+    steps_rank0 = float(res["nrows"].astype(np.int64).clip(1).sum() - len(res["nrows"]))
+    line = {"workload": describe(res), "value": res["value"], "unit": "accepted ray-steps/s", "steps": res["steps"],
+            "warmup": res["warmup"], "ms_per_step": res["ms_per_step"], "kernel_ms": k_ms, "scaling": res["scaling"],
+            "lane_occupancy": res["attempts"] / max(64 * res["wave_attempts"], 1),
+            "accepted_steps_per_launch": res["accepted"] / max(res["steps"], 1)}
+    if res["gather"]:
+        line.update({"gather_ms": res["gather_ms"], "pack_ms": res["pack_ms"], "gather_bytes_into_rank0": res["gather_bytes"],
+                     "kernel_ms_max_over_ranks": res["kernel_ms"]})
+    kind = res["kind"]
+    if kind == "ngo":
+        rf = {"bound": "fp64_valu", "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "achieved": None, "frac": None}
+        if pmc and "error" not in pmc:
+            wave_flop_inst = 2.0 * pmc["SQ_INSTS_VALU_FMA_F64"] + pmc["SQ_INSTS_VALU_MUL_F64"] + pmc["SQ_INSTS_VALU_ADD_F64"]
+            # instructions are counted per wave; lanes switched off by EXEC still occupy the slot.  The live-lane share of
+            # VALU time is SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU).
+            share = pmc["SQ_THREAD_CYCLES_VALU"] / max(64.0 * pmc["SQ_ACTIVE_INST_VALU"], 1.0)
+            share = min(max(share, 0.0), 1.0)
+            ach = wave_flop_inst * 64.0 * share / (k_ms * 1e-3) / 1e12 if k_ms > 0 else None
+            rf.update({"achieved": ach, "frac": ach / FP64_VALU_PEAK_TFLOPS if ach else None,
+                       "issue_slot_TFLOPs": wave_flop_inst * 64.0 / (k_ms * 1e-3) / 1e12 if k_ms > 0 else None,
+                       "live_lane_share_of_valu": share,
+                       "valu_busy": pmc["SQ_ACTIVE_INST_VALU"] / max(pmc["SQ_WAVE_CYCLES"], 1.0),
+                       "fp64_wave_instructions": {k: pmc[k] for k in pmc if k.startswith("SQ_INSTS_VALU_")},
+                       "source": "live: rocprofv3 --pmc child pass of one launch of this workload"})
+        elif pmc:
+            rf["source"] = "unavailable: %s" % pmc["error"]
+        line["roofline"] = rf
+    elif kind == "scattered":
+        rf = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "achieved": None, "frac": None}
+        if pmc and "error" not in pmc and pmc.get("accepted_steps_of_counted_launch"):
+            # the counter passes traced 100k rays of the same launch-set generator against the same sample set: bytes per
+            # accepted step carry over to the 1M-ray launch timed here, the launch time does not
+            bps = pmc["bytes_per_launch"] / pmc["accepted_steps_of_counted_launch"]
+            ach = bps * steps_rank0 / (k_ms * 1e-3) / 1e9 if k_ms > 0 else None
+            rf.update({"achieved": ach, "frac": ach / HBM_PEAK_GBS if ach else None, "traffic_bytes_per_accepted_step": bps,
+                       "traffic": bps * steps_rank0,
+                       "source": pmc["source"] + " on a 100k-ray launch of the same workload (measured bytes per accepted step x "
+                                 "this launch's accepted steps)"})
+        elif pmc:
+            rf["source"] = "unavailable: %s" % pmc.get("error", "no step count from the counter pass")
+        line["roofline"] = rf
+    else:
+        line["roofline"] = {"bound": "hbm", "note": "same kernel as the headline: see roofline"}
+    return line
+
+
+def save_traffic(workload, res, traffic, khash, k_ms):
+    """Keep what the live passes measured (gpurun_out/ is merged back): copy to profiles/ to commit it."""
+    try:
+        d = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        steps = float(res["nrows"].astype(np.int64).clip(1).sum() - len(res["nrows"]))
+        json.dump({"workload": workload, "rays": res["rays_this_rank"], "grid": res["grid"], "kernel_source_sha16": khash,
+                   "kernel": "srt::trace_kernel<%s>" % res["kind"], "FETCH_SIZE_KB": traffic["FETCH_SIZE_KB"],
+                   "WRITE_SIZE_KB": traffic["WRITE_SIZE_KB"],
+                   "correction": "gfx950: FETCH_SIZE doubled (MI355X_MICROARCH.md, HBM section: 128-B requests tallied at 64 B); "
+                                 "WRITE_SIZE as read; x1024 B/KiB.  Counted at the L2's fabric side: Infinity-Cache hits included.",
+                   "hbm_bytes_per_launch": traffic["bytes_per_launch"], "accepted_steps_per_launch": steps,
+                   "hbm_bytes_per_accepted_step": traffic["bytes_per_launch"] / max(steps, 1.0), "kernel_ms_at_collection": k_ms,
+                   "source": "bench.py live PMC passes"}, open(os.path.join(d, "traffic_%s.json" % workload), "w"), indent=1)
+    except Exception:
+        pass
 
 
 def damping_leg(args, api, model, p, slots, d_rows, d_nrows, d_w, dev, torch, nrows):
@@ -347,7 +642,7 @@ def damping_leg(args, api, model, p, slots, d_rows, d_nrows, d_w, dev, torch, nr
     return out
 
 
-def cpu_baseline(args, kind, p, wl, pos0, dir0, w0, grid_n):
+def cpu_baseline(args, kind, p, wl, pos0, dir0, w0, grid_n, extra):
     """The CPU oracle (a port of the reference's algorithm, oracle/srt_oracle.c) timed on the host cores on
     a bounded sample of the SAME workload.  Only the checker/baseline leg touches oracle/."""
     try:
@@ -361,7 +656,12 @@ def cpu_baseline(args, kind, p, wl, pos0, dir0, w0, grid_n):
         om = oracle.Model.interp(F, bounds, wl.QS, wl.MS)
         del F
     elif kind == "scattered":
-        om = oracle.Model.scattered_file(args.points_file, window_scale=1.5, order=2, exact=0, local_window_scale=5.0)
+        from stanford_raytracer_amd import api
+        txt = extra["points_file"] + ".txt"
+        pts, lnN = wl.make_points_config5(5) if args.points in (0, 825_000) else wl.make_points(
+            int(args.points * 0.97), args.points - int(args.points * 0.97), 5, half_width=10.0 * wl.R_E)
+        api.write_points_file(txt, np.concatenate([pts, lnN], axis=1), np.array([-10.0 * wl.R_E, 10.0 * wl.R_E] * 3), wl.QS, wl.MS)
+        om = oracle.Model.scattered_file(txt, window_scale=1.5, order=2, exact=0, local_window_scale=5.0)
     else:
         cfg = os.path.join(tempfile.mkdtemp(), "newray.in")
         with open(cfg, "w") as f:

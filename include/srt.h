@@ -72,7 +72,10 @@ typedef struct srt_params {
 typedef struct srt_model srt_model; /* opaque; owns device copies of all model data */
 
 /* ---- library ---- */
-int srt_init(int device);             /* selects the HIP device; idempotent */
+/* Binds the CALLING THREAD to a HIP device (and makes it the default for threads that never call srt_init).  Models are
+ * created on the calling thread's device and remember it: one host thread per GPU can drive its own model replica
+ * (the CLI's --devices=0,1,..; the reference has no parallel mode, raytracer_driver.f95:1144-1232 is a serial loop). */
+int srt_init(int device);
 const char *srt_last_error(void);
 int srt_device_info(char *name, int name_len, int *cu_count, int64_t *hbm_bytes);
 
@@ -181,6 +184,16 @@ int srt_trace_batch(srt_model *m, const srt_params *p, int64_t nrays, const doub
 int srt_trace_batch_device(srt_model *m, const srt_params *p, int64_t nrays, const double *d_pos0,
                            const double *d_dir0, const double *d_w0, double *d_rows,
                            int32_t *d_nrows, int32_t *d_stopcond, int64_t *d_counters, void *stream);
+/* Packed form of a row buffer for transport (multi-GPU gather; the driver's own loop writes exactly
+ * these rows, raytracer_driver.f95:1197): a ray keeps rows 0, outputper, 2*outputper, .. < nrows, i.e.
+ * kept = (nrows-1)/outputper + 1 of its `slots` slots.  d_offsets[nrays+1] receives the exclusive prefix sums of the
+ * kept counts (d_offsets[nrays] = total), d_packed[total][SRT_ROW] the kept rows of ray 0, ray 1, ... back to back.
+ * capacity_rows = rows d_packed can hold (nrays*slots always suffices; 0 = offsets only).  If the total exceeds the
+ * capacity, the rays that do not fit are left out: compare d_offsets[nrays] with the capacity after synchronising.
+ * All pointers are device memory; asynchronous on `stream`. */
+int srt_pack_rows_device(int32_t slots, int32_t outputper, int64_t nrays, const double *d_rows,
+                         const int32_t *d_nrows, int64_t *d_offsets, double *d_packed, int64_t capacity_rows,
+                         void *stream);
 /* duration in ms of the most recent trace kernel on this model, measured with HIP events on the
  * stream it ran on (synchronises that stream) */
 int srt_last_kernel_ms(srt_model *m, float *ms);

@@ -58,6 +58,9 @@ def lib():
         L.so_model_destroy.argtypes = [C.c_void_p]
         L.so_model_set_igrf.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p]
         L.so_model_nspec.argtypes = [C.c_void_p]
+        L.so_scattered_set_spacing.argtypes = [C.c_void_p, dp, C.c_double]
+        L.so_scattered_radius.restype = C.c_double
+        L.so_scattered_radius.argtypes = [C.c_void_p]
         L.so_plasma_params.argtypes = [C.c_void_p, dp, dp, dp, dp, dp, dp]
         L.so_dispersion_relation.restype = C.c_double
         L.so_dispersion_relation.argtypes = [dp, C.c_double, C.c_int, dp, dp, dp, dp]
@@ -132,6 +135,17 @@ class Model:
                        local_window_scale=5.0, perm_seed=1):
         return cls(lib().so_model_create_scattered_file(os.fsencode(ptsfile), yearday, msec, window_scale, order,
                                                         exact, local_window_scale, perm_seed))
+
+    def set_spacing(self, point, value):
+        """Scattered model: overwrite the stored nearest-sample distance of the sample at exactly `point`."""
+        p = np.ascontiguousarray(point, dtype=np.float64)
+        i = lib().so_scattered_set_spacing(self.h, p.ctypes.data_as(C.POINTER(C.c_double)), float(value))
+        if i < 0:
+            raise ValueError("no sample at %r" % (point,))
+        return i
+
+    def search_radius(self):
+        return lib().so_scattered_radius(self.h)
 
     def set_igrf(self, yearday=2010001, msec=0, coeff_file=None):
         """use_igrf = 1 for this model."""

@@ -156,6 +156,13 @@ program ref_harness
      allocate(data(sz))
      data = transfer(sc_sdp, data)
      call scatsetup(sc_sd, trim(configfile))
+     if (trim(mode) == 'scatroot') then
+        ! which sample the reference's kd-tree has as its root (it depends on the compiler's RNG through randperm,
+        ! scattered_interp_dens_model_adapter.f95:137-165): position, then the stored values (the last one is the
+        ! nearest-sample distance, which the reference leaves at 0 for exactly this sample), then maxnearest
+        write(*,'(a,20es26.17e3)') 'SCAT_ROOT ', sc_sd%tree%point, sc_sd%tree%val, sc_sd%maxnearest
+        stop
+     end if
      call dispatch(fscat, 1.0e-6_DP)
   else
      print *, 'ref_harness: unsupported modelnum'

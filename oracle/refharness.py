@@ -85,3 +85,17 @@ def run_rays(model, rays, rayout=None, threads=1, **kw):
         pos += 32 * T
         out.append({"raynum": raynum, "stopcond": stop, "rows": rows})
     return out, timing
+
+
+def scattered_root(model):
+    """The sample at the root of the reference's kd-tree for a modelnum-4 model: (point[3], vals[nspec+1], maxnearest)."""
+    with tempfile.TemporaryDirectory() as td:
+        fin = os.path.join(td, "in.txt")
+        _write_rows(fin, np.zeros((1, 3)))
+        cmd = [EXE, "--mode=scatroot", "--in=%s" % fin, "--out=%s" % os.path.join(td, "out.bin")] + _model_flags(model)
+        res = subprocess.run(cmd, check=True, stdout=subprocess.PIPE, text=True)
+    for line in res.stdout.splitlines():
+        if line.startswith("SCAT_ROOT"):
+            v = np.array([float(t) for t in line.split()[1:]])
+            return v[:3], v[3:-1], float(v[-1])
+    raise RuntimeError("ref_harness gave no SCAT_ROOT line")

@@ -78,6 +78,8 @@ long so_trace_batch(so_model *m, const so_params *p, long nrays, const double *p
                     int *nrows, int *stopcond, int nthreads);
 
 /* helpers exposed for tests */
+int so_scattered_set_spacing(so_model *m, const double p[3], double value); /* srt_oracle_scattered.c */
+double so_scattered_radius(const so_model *m);                              /* maxnearest * window_scale */
 void so_dipole_tilt(int yearday, int msec, double *mu);
 void so_bfield(so_model *m, const double x[3], double B0[3]);
 double so_speed_of_light(void);

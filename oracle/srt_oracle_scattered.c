@@ -388,3 +388,19 @@ so_model *so_model_create_scattered_file(const char *ptsfile, int yearday, int m
   so_dipole_tilt(yearday, msec, &m->mu);
   return m;
 }
+
+/* Test helper: overwrite the stored nearest-sample distance of the sample at exactly p (val[nspec]) -- e.g. 0 for the
+ * sample that is the root of the REFERENCE's kd-tree (it seeds kdtree_nearest's `best` with the root, so the root's own
+ * "nearest other sample" is itself; which sample that is comes from the reference build, tests/golden/
+ * scattered_o3_golden.npz: ref_root_index).  Returns the node index, or -1 if no sample sits at p. */
+int so_scattered_set_spacing(so_model *m, const double p[3], double value) {
+  if (!m || m->kind != 4) return -1;
+  struct so_scattered *sc = m->sc;
+  for (int i = 0; i < sc->n; i++)
+    if (sc->nodes[i].p[0] == p[0] && sc->nodes[i].p[1] == p[1] && sc->nodes[i].p[2] == p[2]) {
+      sc->nodes[i].val[sc->nspec] = value;
+      return i;
+    }
+  return -1;
+}
+double so_scattered_radius(const so_model *m) { return (m && m->kind == 4) ? m->sc->maxnearest * m->sc->window_scale : 0.0; }

@@ -97,6 +97,7 @@ def lib():
     L.srt_rows_per_ray.restype = C.c_int32
     L.srt_trace_batch.argtypes = [vp, C.POINTER(Params), C.c_int64, dp, dp, dp, dp, ip, ip, C.POINTER(C.c_int64)]
     L.srt_trace_batch_device.argtypes = [vp, C.POINTER(Params), C.c_int64, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.srt_pack_rows_device.argtypes = [C.c_int32, C.c_int32, C.c_int64, vp, vp, vp, vp, C.c_int64, vp]
     L.srt_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.srt_launch_ms.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
     L.srt_read_rays_file.argtypes = [C.c_char_p, C.POINTER(dp), C.POINTER(dp), C.POINTER(dp)]

@@ -49,7 +49,7 @@ def build(force=False, verbose=False):
         subprocess.check_call(cmd)
     cli_src = [os.path.join(CSRC, f) for f in CLI_SRCS]
     if all(os.path.exists(s) for s in cli_src) and (force or _stale(CLI, cli_src + [LIB])):
-        cmd = [_hipcc(), "-O2", "-std=c++17", "-o", CLI] + cli_src + \
+        cmd = [_hipcc(), "-O2", "-std=c++17", "-pthread", "-o", CLI] + cli_src + \
               ["-L" + LIBDIR, "-lsrt_hip", "-Wl,-rpath,$ORIGIN/../lib"]
         if verbose:
             print(" ".join(cmd))

@@ -43,25 +43,36 @@ extern "C" const char *srt_last_error(void) { return g_err.c_str(); }
                            hipGetErrorString(e_));                                            \
   } while (0)
 
-static int g_device = -1;
+// Device selection.  srt_init(device) binds the CALLING THREAD to a device (and makes it the process default for
+// threads that never called srt_init): one host thread per GPU may drive its own models concurrently (the CLI's
+// --devices=0,1,..).  A model remembers the device it was created on, and every entry point that takes a model
+// switches to that device first, whichever thread calls it.
+#include <atomic>
+static std::atomic<int> g_default_device{-1};
+static thread_local int t_device = -1;
 extern "C" int srt_init(int device) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
     return srt_set_error(SRT_EDEVICE, "no HIP device available (this library has no CPU path)");
   if (device < 0 || device >= n) return srt_set_error(SRT_EINVAL, "device %d out of range (%d devices)", device, n);
   HIP_OK(hipSetDevice(device));
-  g_device = device;
+  t_device = device;
+  g_default_device.store(device);
   return SRT_OK;
 }
 static int ensure_init() {
-  if (g_device >= 0) return hipSetDevice(g_device) == hipSuccess ? SRT_OK : srt_set_error(SRT_EDEVICE, "hipSetDevice failed");
-  return srt_init(0);
+  int dev = t_device >= 0 ? t_device : g_default_device.load();
+  if (dev < 0) return srt_init(0);
+  if (hipSetDevice(dev) != hipSuccess) return srt_set_error(SRT_EDEVICE, "hipSetDevice(%d) failed", dev);
+  t_device = dev;
+  return SRT_OK;
 }
+static int current_device() { return t_device >= 0 ? t_device : 0; }
 extern "C" int srt_device_info(char *name, int name_len, int *cu_count, int64_t *hbm_bytes) {
   int rc = ensure_init();
   if (rc) return rc;
   hipDeviceProp_t p;
-  HIP_OK(hipGetDeviceProperties(&p, g_device));
+  HIP_OK(hipGetDeviceProperties(&p, current_device()));
   if (name && name_len > 0) snprintf(name, name_len, "%s (%s)", p.name, p.gcnArchName);
   if (cu_count) *cu_count = p.multiProcessorCount;
   if (hbm_bytes) *hbm_bytes = (int64_t)p.totalGlobalMem;
@@ -71,6 +82,7 @@ extern "C" int srt_device_info(char *name, int name_len, int *cu_count, int64_t 
 // ------------------------------------------------------------------------------------------ model
 struct srt_model {
   int kind = 0, nspec = 0;
+  int device = 0; // the HIP device the tables live on
   Common cm{};
   NgoModel ngo{};
   InterpModel interp{};
@@ -101,6 +113,13 @@ struct srt_model {
   LaunchSlot slot[NSLOT];
   int next_slot = 0, last_slot = -1;
 };
+
+// switch the calling thread to the model's device
+static int ensure_model(const srt_model *m) {
+  if (hipSetDevice(m->device) != hipSuccess) return srt_set_error(SRT_EDEVICE, "hipSetDevice(%d) failed", m->device);
+  t_device = m->device;
+  return SRT_OK;
+}
 
 static void fill_common(Common &cm, int nspec, const double *qs, const double *ms, int yearday, int msec) {
   memset(&cm, 0, sizeof cm);
@@ -140,7 +159,8 @@ static int model_finish(srt_model *m) {
     HIP_OK(hipMemcpy(m->d_model, &m->scat, sizeof(ScatteredModel), hipMemcpyHostToDevice));
   }
   hipDeviceProp_t p;
-  HIP_OK(hipGetDeviceProperties(&p, g_device));
+  m->device = current_device();
+  HIP_OK(hipGetDeviceProperties(&p, m->device));
   m->cu_count = p.multiProcessorCount;
   for (auto &sl : m->slot) {
     HIP_OK(hipEventCreate(&sl.ev0));
@@ -175,7 +195,7 @@ extern "C" int srt_model_set_field(srt_model *m, int use_igrf, int use_tsyganenk
   if (!m) return srt_set_error(SRT_EINVAL, "null model");
   if (use_tsyganenko != 0 && use_tsyganenko != 1) return srt_set_error(SRT_EINVAL, "use_tsyganenko must be 0 or 1");
   if (use_igrf != 0 && use_igrf != 1) return srt_set_error(SRT_EINVAL, "use_igrf must be 0 or 1");
-  int rc = ensure_init();
+  int rc = ensure_model(m);
   if (rc) return rc;
   FieldConst &f = m->cm.fld;
   if (use_igrf || use_tsyganenko) { // both need geopack's RECALC_08 for the date: coefficients, GEO->GSM matrix, dipole tilt
@@ -209,7 +229,7 @@ extern "C" int srt_model_set_field(srt_model *m, int use_igrf, int use_tsyganenk
 // T04_s's PARMOD (driver flags --tsyganenko_Pdyn, _Dst, _ByIMF, _BzIMF, _W1 .. _W6; raytracer_driver.f95:292-341)
 extern "C" int srt_model_set_tsyganenko_params(srt_model *m, const double parmod[10]) {
   if (!m || !parmod) return srt_set_error(SRT_EINVAL, "null argument");
-  int rc = ensure_init();
+  int rc = ensure_model(m);
   if (rc) return rc;
   for (int i = 0; i < 10; ++i) m->cm.fld.parmod[i] = (float)parmod[i]; // real(parmod)
   HIP_OK(hipMemcpy(m->d_common, &m->cm, sizeof(Common), hipMemcpyHostToDevice));
@@ -623,7 +643,7 @@ static int check_grid_request(srt_model *src, int nx, int ny, int nz, const doub
   if (nx < 2 || ny < 2 || nz < 2) return srt_set_error(SRT_EINVAL, "grid must have >= 2 nodes per axis");
   if ((size_t)(nx + 1) * (ny + 1) * (nz + 1) >= (size_t)1 << 31) return srt_set_error(SRT_EINVAL, "grid too large");
   if (!(bounds[1] > bounds[0]) || !(bounds[3] > bounds[2]) || !(bounds[5] > bounds[4])) return srt_set_error(SRT_EINVAL, "empty bounds");
-  return ensure_init();
+  return ensure_model(src);
 }
 
 extern "C" int srt_build_grid(srt_model *src, int compder, int nx, int ny, int nz, const double bounds[6], double *F,
@@ -681,8 +701,8 @@ extern "C" int srt_model_create_interp_file(const char *gridfile, int yearday, i
 extern "C" int srt_model_create_scattered_file(const char *ptsfile, int yearday, int msec, double window_scale,
                                                int order, int exact, double local_window_scale, srt_model **out) {
   if (!ptsfile || !out) return srt_set_error(SRT_EINVAL, "null argument");
-  if (order < 0 || order > 2)
-    return srt_set_error(SRT_EINVAL, "scattered_interp_order=%d: orders 0..2 are built (order 3 needs a 20x20 system per lane)", order);
+  if (order < 0 || order > 3) // tabular_monomials covers degrees 0..3 (lsinterp_mod.f95:76-99); beyond: generate_monomials, not built
+    return srt_set_error(SRT_EINVAL, "scattered_interp_order=%d: orders 0..3 are supported", order);
   if (!(window_scale > 0) || !(local_window_scale > 0)) return srt_set_error(SRT_EINVAL, "window scales must be > 0");
   int rc = ensure_init();
   if (rc) return rc;
@@ -773,7 +793,7 @@ extern "C" int srt_plasma_params(srt_model *m, int64_t n, const double *x, doubl
                                  double *nus, double *B0) {
   if (!m || !x || n < 0) return srt_set_error(SRT_EINVAL, "bad argument");
   if (n == 0) return SRT_OK;
-  int rc = ensure_init();
+  int rc = ensure_model(m);
   if (rc) return rc;
   DevBuf dx, dout;
   if ((rc = upload(dx, x, 3 * n))) return rc;
@@ -801,7 +821,7 @@ extern "C" int srt_plasma_params(srt_model *m, int64_t n, const double *x, doubl
 extern "C" int srt_dispersion(srt_model *m, int64_t n, const double *x, const double *k, const double *w, double *out) {
   if (!m || !x || !k || !w || !out || n < 0) return srt_set_error(SRT_EINVAL, "bad argument");
   if (n == 0) return SRT_OK;
-  int rc = ensure_init();
+  int rc = ensure_model(m);
   if (rc) return rc;
   DevBuf dx, dk, dw, dout;
   if ((rc = upload(dx, x, 3 * n)) || (rc = upload(dk, k, 3 * n)) || (rc = upload(dw, w, n))) return rc;
@@ -836,7 +856,7 @@ extern "C" int srt_is_right_handed(int64_t n, const double *in, int32_t *out) {
 extern "C" int srt_gradients(srt_model *m, int64_t n, const double *x, const double *k, const double *w, double del, double *out) {
   if (!m || !x || !k || !w || !out || n < 0) return srt_set_error(SRT_EINVAL, "bad argument");
   if (n == 0) return SRT_OK;
-  int rc = ensure_init();
+  int rc = ensure_model(m);
   if (rc) return rc;
   DevBuf dx, dk, dw, dout;
   if ((rc = upload(dx, x, 3 * n)) || (rc = upload(dk, k, 3 * n)) || (rc = upload(dw, w, n))) return rc;
@@ -859,7 +879,7 @@ extern "C" int srt_gradients(srt_model *m, int64_t n, const double *x, const dou
 extern "C" int srt_rk_step(srt_model *m, int64_t n, const double *args, const double *dt, double del, double *out) {
   if (!m || !args || !dt || !out || n < 0) return srt_set_error(SRT_EINVAL, "bad argument");
   if (n == 0) return SRT_OK;
-  int rc = ensure_init();
+  int rc = ensure_model(m);
   if (rc) return rc;
   DevBuf da, dd, dout;
   if ((rc = upload(da, args, 7 * n)) || (rc = upload(dd, dt, n))) return rc;
@@ -923,7 +943,7 @@ extern "C" int srt_build_samples(srt_model *src, const srt_sampler_params *sp, i
   if (sp->n_zero_altitude < 0 || sp->n_iri_pad < 0 || sp->n_initial_radial < 0 || sp->n_initial_uniform < 0 || sp->max_recursion < 0 ||
       sp->numincrease < 0)
     return srt_set_error(SRT_EINVAL, "negative count");
-  int rc = ensure_init();
+  int rc = ensure_model(src);
   if (rc) return rc;
   const int nspec = src->nspec, ninc = sp->numincrease ? sp->numincrease : 5;
   if (ninc > WAVE) return srt_set_error(SRT_EINVAL, "numincrease > %d", WAVE);
@@ -1146,7 +1166,7 @@ extern "C" int srt_trace_batch_device(srt_model *m, const srt_params *p, int64_t
     return srt_set_error(SRT_EINVAL, "bad argument");
   int rc = check_params(p);
   if (rc) return rc;
-  if ((rc = ensure_init())) return rc;
+  if ((rc = ensure_model(m))) return rc;
   hipStream_t st = (hipStream_t)stream;
   TraceArgs a;
   a.pos0 = d_pos0;
@@ -1365,6 +1385,72 @@ extern "C" int srt_damping(const srt_damping_params *dp, int nspec, const double
 }
 
 
+// ---- packed trajectory rows (multi-GPU gather, SURVEY 8e: only the rows a ray produced travel) ----
+// kept rows of a ray = rows 0, outputper, 2*outputper, .. < nrows  (raytracer_driver.f95:1197)
+struct KeptRows {
+  const int32_t *nrows;
+  int32_t outputper, slots;
+  __host__ __device__ long long operator()(long long i) const {
+    const int32_t n = nrows[i];
+    int32_t k = n > 0 ? (n - 1) / outputper + 1 : 0;
+    return k < slots ? k : slots;
+  }
+};
+__global__ void pack_total_kernel(KeptRows kr, long long nrays, long long *offsets) {
+  offsets[nrays] = offsets[nrays - 1] + kr(nrays - 1);
+}
+// one wave per ray: the ray's kept rows are one contiguous run of 160-B records in both buffers
+__global__ __launch_bounds__(256) void pack_rows_kernel(long long nrays, int slots, const double *__restrict__ rows,
+                                                        const long long *__restrict__ offsets, double *__restrict__ packed,
+                                                        long long capacity) {
+  const int lane = threadIdx.x & 63;
+  for (long long ray = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); ray < nrays; ray += (long long)gridDim.x * 4) {
+    const long long o0 = offsets[ray], o1 = offsets[ray + 1];
+    if (o1 > capacity) continue; // the caller sees offsets[nrays] > capacity and fails the call
+    const long long ndbl = (o1 - o0) * SRT_ROW;
+    const double2 *src = (const double2 *)(rows + (size_t)ray * slots * SRT_ROW);
+    double2 *dst = (double2 *)(packed + (size_t)o0 * SRT_ROW);
+    for (long long q = lane; q < ndbl / 2; q += 64) dst[q] = src[q];
+  }
+}
+
+extern "C" int srt_pack_rows_device(int32_t slots, int32_t outputper, int64_t nrays, const double *d_rows,
+                                    const int32_t *d_nrows, int64_t *d_offsets, double *d_packed,
+                                    int64_t capacity_rows, void *stream) {
+  if (!d_offsets || nrays < 0 || slots < 1 || outputper < 1 || capacity_rows < 0 ||
+      (nrays > 0 && (!d_rows || !d_nrows || (!d_packed && capacity_rows > 0))))
+    return srt_set_error(SRT_EINVAL, "bad argument");
+  int rc = ensure_init();
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if (nrays == 0) {
+    HIP_OK(hipMemsetAsync(d_offsets, 0, sizeof(int64_t), st));
+    return SRT_OK;
+  }
+  if (nrays >= (1ll << 31) - 1) return srt_set_error(SRT_EINVAL, "too many rays for one pack call");
+  // offsets[0 .. nrays] = exclusive prefix sums of the kept-row counts (one extra item so the total lands in [nrays])
+  static_assert(sizeof(long long) == sizeof(int64_t), "int64");
+  auto counts = hipcub::TransformInputIterator<long long, KeptRows, hipcub::CountingInputIterator<long long>>(
+      hipcub::CountingInputIterator<long long>(0), KeptRows{d_nrows, outputper, slots});
+  size_t need = 0;
+  HIP_OK(hipcub::DeviceScan::ExclusiveSum(nullptr, need, counts, (long long *)d_offsets, (int)nrays, st));
+  void *tmp = nullptr;
+  HIP_OK(hipMallocAsync(&tmp, need ? need : 16, st));
+  hipError_t e = hipcub::DeviceScan::ExclusiveSum(tmp, need, counts, (long long *)d_offsets, (int)nrays, st);
+  if (e == hipSuccess) e = hipFreeAsync(tmp, st);
+  HIP_OK(e);
+  // offsets[nrays] = offsets[nrays-1] + kept(nrays-1)
+  hipLaunchKernelGGL(pack_total_kernel, dim3(1), dim3(1), 0, st, KeptRows{d_nrows, outputper, slots}, (long long)nrays, (long long *)d_offsets);
+  if (capacity_rows > 0) {
+    long long blocks = (nrays + 3) / 4;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (long long)nrays, (int)slots, d_rows,
+                       (const long long *)d_offsets, d_packed, (long long)capacity_rows);
+  }
+  HIP_OK(hipGetLastError());
+  return SRT_OK;
+}
+
 // AoS [n][3] -> SoA [3][n]
 __global__ void aos_to_soa3(const double *in, double *out, long long n) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1385,7 +1471,7 @@ extern "C" int srt_trace_batch(srt_model *m, const srt_params *p, int64_t nrays,
     if (accepted_steps) *accepted_steps = 0;
     return SRT_OK;
   }
-  if ((rc = ensure_init())) return rc;
+  if ((rc = ensure_model(m))) return rc;
   const int slots = srt_rows_per_ray(p);
   const size_t nrow_d = (size_t)nrays * slots * SRT_ROW;
   DevBuf a_pos, a_dir, s_pos, s_dir, dw, drows;

@@ -10,7 +10,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/srt.h"
@@ -128,7 +130,7 @@ int main(int argc, char **argv) {
          "  model 3: --interp_interpfile --yearday --milliseconds_day --use_tsyganenko=0|1 --use_igrf=0|1\n"
          "  model 4: model 3 flags + --scattered_interp_window_scale --scattered_interp_order\n"
          "           --scattered_interp_exact --scattered_interp_local_window_scale\n"
-         "  extra:   --device=N  --first_attempt_policy=0|1  --chunk_rays=N  --ray_order=0|1\n"
+         "  extra:   --device=N | --devices=0,1,..  --first_attempt_policy=0|1  --chunk_rays=N  --ray_order=0|1\n"
          "  tools:   --grid2bin_in=<text grid> --grid2bin_out=<binary grid>   (convert and exit; --interp_interpfile\n"
          "           accepts either form);  --pts2bin_in / --pts2bin_out: the same for model-4 sample files\n"
          "           --buildsamples=1 --filename=<out> --minx .. --maxz --n_initial_uniform ... (the reference's random grid\n"
@@ -214,17 +216,30 @@ int main(int argc, char **argv) {
   }
   p.outputper = 1;
   get_int("outputper", p.outputper);
+  if (p.outputper < 1) p.outputper = 1; // the reference's mod(i-1, outputper) with outputper <= 0 is undefined; the library clamps too
   get_int("device", device);
   get_int("first_attempt_policy", p.first_attempt_policy);
   get_int("ray_order", p.ray_order);
   get_int("chunk_rays", chunk);
-  srt_model *m = nullptr;
+  // ours: --devices=0,1,.. = one host thread and one model replica per GPU, contiguous shards of the ray file
+  // (ceil(n/ndev) rays each), records written in ray order.  Default: the one device of --device.
+  std::vector<int> devices;
   {
-    double del = 0.0;
-    int rc = make_model(device, &m, &del);
-    if (rc) return rc;
-    p.del = del;
+    std::string dl;
+    if (getopt_named("devices", dl)) {
+      const char *c = dl.c_str();
+      while (*c) {
+        char *end = nullptr;
+        long v = strtol(c, &end, 10);
+        if (end == c) break;
+        devices.push_back((int)v);
+        c = (*end == ',') ? end + 1 : end;
+        if (end && *end && *end != ',') break;
+      }
+    }
+    if (devices.empty()) devices.push_back(device);
   }
+  const int ndev = (int)devices.size();
   double *pos0 = nullptr, *dir0 = nullptr, *w0 = nullptr;
   int64_t nrays = srt_read_rays_file(rays_path.c_str(), &pos0, &dir0, &w0);
   if (nrays < 0) {
@@ -243,15 +258,6 @@ int main(int argc, char **argv) {
     if (get_real("damping_kT_eV", kTeV)) dpar.kT = kTeV * 1.60217646e-19;
     get_real("damping_tol", dpar.tol);
   }
-  const int slots = srt_rows_per_ray(&p);
-  double qs[SRT_MAXSPEC], ms[SRT_MAXSPEC];
-  srt_model_species(m, qs, ms);
-  const int nspec = srt_model_nspec(m);
-  // bound host/device memory: at most ~2 GiB of trajectory rows per launch
-  int64_t per = (int64_t)slots * SRT_ROW * 8;
-  int64_t maxchunk = chunk > 0 ? chunk : ((int64_t)2 << 30) / (per > 0 ? per : 1);
-  if (maxchunk < 64) maxchunk = 64;
-  int64_t total_steps = 0;
   // the reference opens the output with status="replace" even when there are no rays
   {
     FILE *f = fopen(out_path.c_str(), "w");
@@ -261,39 +267,118 @@ int main(int argc, char **argv) {
     }
     fclose(f);
   }
-  for (int64_t lo = 0; lo < nrays; lo += maxchunk) {
-    int64_t n = nrays - lo < maxchunk ? nrays - lo : maxchunk;
-    std::vector<double> rows((size_t)n * slots * SRT_ROW);
-    std::vector<int32_t> nrows(n), stop(n);
-    int64_t steps = 0;
-    CHECK(srt_trace_batch(m, &p, n, pos0 + 3 * lo, dir0 + 3 * lo, w0 + lo, rows.data(), nrows.data(), stop.data(), &steps));
-    total_steps += steps;
-    CHECK(srt_write_ray_file(out_path.c_str(), 1, lo + 1, n, &p, nspec, qs, ms, w0 + lo, rows.data(), nrows.data(), stop.data()));
-    if (!damp_path.empty()) {
-      // the MATLAB post-processor (matlab/damping/test_dampray.m) on the rows just traced: one record per kept row
-      std::vector<double> rate((size_t)n * slots), mag((size_t)n * slots);
-      std::vector<int32_t> flag((size_t)n * slots);
-      CHECK(srt_damping(&dpar, nspec, qs, ms, slots, p.outputper, n, rows.data(), nrows.data(), w0 + lo, rate.data(), mag.data(), flag.data()));
-      FILE *f = fopen(damp_path.c_str(), lo == 0 ? "w" : "a");
+  // one shard per device; shard k writes <out>.part<k> (or <out> itself when there is one device), concatenated below
+  struct Shard {
+    int device = 0;
+    int64_t lo = 0, hi = 0, steps = 0;
+    std::string out, damp;
+    int rc = 0;
+  };
+  std::vector<Shard> shards(ndev);
+  const int64_t per_dev = (nrays + ndev - 1) / ndev;
+  for (int k = 0; k < ndev; ++k) {
+    Shard &sh = shards[k];
+    sh.device = devices[k];
+    sh.lo = std::min<int64_t>((int64_t)k * per_dev, nrays);
+    sh.hi = std::min<int64_t>(sh.lo + per_dev, nrays);
+    sh.out = ndev == 1 ? out_path : out_path + ".part" + std::to_string(k);
+    sh.damp = damp_path.empty() ? std::string() : (ndev == 1 ? damp_path : damp_path + ".part" + std::to_string(k));
+  }
+  auto run_shard = [&](Shard &sh) -> int {
+    srt_model *m = nullptr;
+    double del = 0.0;
+    int rc = make_model(sh.device, &m, &del);
+    if (rc) return rc;
+    srt_params q = p;
+    q.del = del;
+    const int slots = srt_rows_per_ray(&q);
+    double qs[SRT_MAXSPEC], ms[SRT_MAXSPEC];
+    srt_model_species(m, qs, ms);
+    const int nspec = srt_model_nspec(m);
+    // bound host/device memory: at most ~2 GiB of trajectory rows per launch
+    int64_t per = (int64_t)slots * SRT_ROW * 8;
+    int64_t maxchunk = chunk > 0 ? chunk : ((int64_t)2 << 30) / (per > 0 ? per : 1);
+    if (maxchunk < 64) maxchunk = 64;
+    if (ndev > 1) {
+      FILE *f = fopen(sh.out.c_str(), "w");
       if (!f) {
-        fprintf(stderr, "raytracer: cannot open %s\n", damp_path.c_str());
+        fprintf(stderr, "raytracer: cannot open %s\n", sh.out.c_str());
         return 1;
       }
-      for (int64_t i = 0; i < n; ++i) {
-        const int kept = nrows[i] > 0 ? (nrows[i] - 1) / p.outputper + 1 : 0;
-        for (int r = 0; r < kept && r < slots; ++r) {
-          const size_t idx = (size_t)i * slots + r;
-          fprintf(f, "%10lld%10d%25.15E%25.15E%25.15E%10d\n", (long long)(lo + i + 1), r * p.outputper + 1, rows[idx * SRT_ROW], rate[idx], mag[idx],
-                  (int)flag[idx]);
-        }
-      }
       fclose(f);
+    }
+    for (int64_t lo = sh.lo; lo < sh.hi; lo += maxchunk) {
+      int64_t n = sh.hi - lo < maxchunk ? sh.hi - lo : maxchunk;
+      std::vector<double> rows((size_t)n * slots * SRT_ROW);
+      std::vector<int32_t> nrows(n), stop(n);
+      int64_t steps = 0;
+      CHECK(srt_trace_batch(m, &q, n, pos0 + 3 * lo, dir0 + 3 * lo, w0 + lo, rows.data(), nrows.data(), stop.data(), &steps));
+      sh.steps += steps;
+      CHECK(srt_write_ray_file(sh.out.c_str(), 1, lo + 1, n, &q, nspec, qs, ms, w0 + lo, rows.data(), nrows.data(), stop.data()));
+      if (!sh.damp.empty()) {
+        // the MATLAB post-processor (matlab/damping/test_dampray.m) on the rows just traced: one record per kept row
+        std::vector<double> rate((size_t)n * slots), mag((size_t)n * slots);
+        std::vector<int32_t> flag((size_t)n * slots);
+        CHECK(srt_damping(&dpar, nspec, qs, ms, slots, q.outputper, n, rows.data(), nrows.data(), w0 + lo, rate.data(), mag.data(), flag.data()));
+        FILE *f = fopen(sh.damp.c_str(), lo == sh.lo ? "w" : "a");
+        if (!f) {
+          fprintf(stderr, "raytracer: cannot open %s\n", sh.damp.c_str());
+          return 1;
+        }
+        for (int64_t i = 0; i < n; ++i) {
+          const int kept = nrows[i] > 0 ? (nrows[i] - 1) / q.outputper + 1 : 0;
+          for (int r = 0; r < kept && r < slots; ++r) {
+            const size_t idx = (size_t)i * slots + r;
+            fprintf(f, "%10lld%10d%25.15E%25.15E%25.15E%10d\n", (long long)(lo + i + 1), r * q.outputper + 1, rows[idx * SRT_ROW], rate[idx], mag[idx],
+                    (int)flag[idx]);
+          }
+        }
+        fclose(f);
+      }
+    }
+    srt_model_destroy(m);
+    return 0;
+  };
+  if (ndev == 1) {
+    shards[0].rc = run_shard(shards[0]);
+  } else {
+    std::vector<std::thread> th;
+    for (int k = 0; k < ndev; ++k) th.emplace_back([&, k] { shards[k].rc = run_shard(shards[k]); });
+    for (auto &t : th) t.join();
+  }
+  int64_t total_steps = 0;
+  for (auto &sh : shards) {
+    if (sh.rc) return sh.rc;
+    total_steps += sh.steps;
+  }
+  if (ndev > 1) { // records in ray order: shard 0's file, then shard 1's, ...
+    auto cat = [](const std::string &dst, const std::vector<std::string> &parts) -> bool {
+      FILE *o = fopen(dst.c_str(), "w");
+      if (!o) return false;
+      std::vector<char> buf(1 << 22);
+      for (auto &pn : parts) {
+        FILE *i = fopen(pn.c_str(), "r");
+        if (!i) continue; // an empty shard (fewer rays than devices) wrote nothing
+        size_t got;
+        while ((got = fread(buf.data(), 1, buf.size(), i)) > 0) fwrite(buf.data(), 1, got, o);
+        fclose(i);
+        remove(pn.c_str());
+      }
+      return fclose(o) == 0;
+    };
+    std::vector<std::string> parts, dparts;
+    for (auto &sh : shards) {
+      parts.push_back(sh.out);
+      if (!sh.damp.empty()) dparts.push_back(sh.damp);
+    }
+    if (!cat(out_path, parts) || (!damp_path.empty() && !cat(damp_path, dparts))) {
+      fprintf(stderr, "raytracer: cannot assemble %s\n", out_path.c_str());
+      return 1;
     }
   }
   printf(" %lld rays, %lld accepted steps\n", (long long)nrays, (long long)total_steps);
   srt_free(pos0);
   srt_free(dir0);
   srt_free(w0);
-  srt_model_destroy(m);
   return 0;
 }

@@ -11,6 +11,7 @@
 //   A = sum_i w_i m_i m_i^T,  b_s = sum_i w_i m_i lnN_s(i),  w_i = 0.5*etainv(r_i) (= dinv_i^2), m_i = monomials(x_i - x)
 //   solve A y = e_1 (Cholesky, dposv 'U'), ln N_s(x) = y . b_s           [== dot(aa, vals) with aa = (E y) * dinv]
 #pragma once
+#include <type_traits>
 #include <utility>
 #include "srt_models.hpp"
 
@@ -59,43 +60,74 @@ __device__ unsigned long long srt_phase_cycles[16];
 #define SRT_PHASE_FLUSH(ldsbase) do {} while (0)
 #endif
 
-// Order 2 on the shared path: A = sum w m m^T has 55 entries but only 35 different sums -- the moments sum w x^a y^b z^c,
-// a + b + c <= 4 (m_a m_c is a monomial of degree <= 4).  35 + 40 running sums fit the 256 vector registers next to the
-// record being folded in; 55 + 40 do not (the rest would sit in accumulation registers and be copied in and out per
-// neighbour).  Monomials by degree; MOM_E[i] = exponents of x, y, z.
-struct Moments {
-  static constexpr int N = 35;
-  static constexpr int E[N][3] = {{0, 0, 0}, {1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {2, 0, 0}, {1, 1, 0}, {1, 0, 1}, {0, 2, 0}, {0, 1, 1},
-                                  {0, 0, 2}, {3, 0, 0}, {2, 1, 0}, {2, 0, 1}, {1, 2, 0}, {1, 1, 1}, {1, 0, 2}, {0, 3, 0}, {0, 2, 1},
-                                  {0, 1, 2}, {0, 0, 3}, {4, 0, 0}, {3, 1, 0}, {3, 0, 1}, {2, 2, 0}, {2, 1, 1}, {2, 0, 2}, {1, 3, 0},
-                                  {1, 2, 1}, {1, 1, 2}, {1, 0, 3}, {0, 4, 0}, {0, 3, 1}, {0, 2, 2}, {0, 1, 3}, {0, 0, 4}};
-  static constexpr int find(int a, int b, int c) {
-    for (int i = 0; i < N; ++i)
-      if (E[i][0] == a && E[i][1] == b && E[i][2] == c) return i;
-    return -1;
-  }
+// Orders 2 and 3: A = sum w m m^T has J (J + 1) / 2 entries (55 / 210) but only N different sums -- the moments
+// sum w x^a y^b z^c, a + b + c <= 2 * order (m_a m_c is a monomial of that degree): N = 35 / 84.  35 + 40 running sums fit the 256
+// vector registers next to the record being folded in; 55 + 40 do not (the rest would sit in accumulation registers and be
+// copied in and out per neighbour); for order 3, 84 + 80 sums fit the unified 512 registers, 210 + 80 fit nothing.
+namespace mom {
+constexpr int count(int deg) { return (deg + 1) * (deg + 2) * (deg + 3) / 6; } // monomials of degree <= deg in 3 variables
+// moment order: by degree; within a degree x descending, then y descending
+constexpr int find(int a, int b, int c) {
+  const int d = a + b + c;
+  int idx = d > 0 ? count(d - 1) : 0;
+  for (int aa = d; aa >= 0; --aa)
+    for (int bb = d - aa; bb >= 0; --bb) {
+      if (aa == a && bb == b) return idx;
+      ++idx;
+    }
+  return -1;
+}
+constexpr int exponent(int i, int ax) { // exponent of axis ax (0 x, 1 y, 2 z) of moment i
+  int idx = 0;
+  for (int d = 0; d < 16; ++d)
+    for (int aa = d; aa >= 0; --aa)
+      for (int bb = d - aa; bb >= 0; --bb) {
+        if (idx == i) return ax == 0 ? aa : (ax == 1 ? bb : d - aa - bb);
+        ++idx;
+      }
+  return -1;
+}
+// tabular_monomials, 3 dimensions (lsinterp_mod.f95:76-99): lexicographic in (x, y, z), total degree <= order
+constexpr int tab_exponent(int order, int j, int ax) {
+  int idx = 0;
+  for (int x = 0; x <= order; ++x)
+    for (int y = 0; y <= order - x; ++y)
+      for (int z = 0; z <= order - x - y; ++z) {
+        if (idx == j) return ax == 0 ? x : (ax == 1 ? y : z);
+        ++idx;
+      }
+  return -1;
+}
+} // namespace mom
+
+template <int ORDER>
+struct MomentsT {
+  static constexpr int J = mom::count(ORDER);
+  static constexpr int N = mom::count(2 * ORDER);
+  static constexpr int NT = J * (J + 1) / 2;
   // the monomial is its parent times one coordinate: the last non-zero exponent (z, else y, else x) reduced by one
-  static constexpr int axis(int i) { return E[i][2] > 0 ? 2 : (E[i][1] > 0 ? 1 : 0); }
+  static constexpr int axis(int i) { return mom::exponent(i, 2) > 0 ? 2 : (mom::exponent(i, 1) > 0 ? 1 : 0); }
   static constexpr int parent(int i) {
-    return axis(i) == 2 ? find(E[i][0], E[i][1], E[i][2] - 1) : (axis(i) == 1 ? find(E[i][0], E[i][1] - 1, 0) : find(E[i][0] - 1, 0, 0));
+    return mom::find(mom::exponent(i, 0) - (axis(i) == 0), mom::exponent(i, 1) - (axis(i) == 1), mom::exponent(i, 2) - (axis(i) == 2));
   }
-  // tabular_monomials of order 2 (lsinterp_mod.f95:70-99): exponents (x, y, z) of m_0 .. m_9
-  static constexpr int ME[10][3] = {{0, 0, 0}, {0, 0, 1}, {0, 0, 2}, {0, 1, 0}, {0, 1, 1}, {0, 2, 0}, {1, 0, 0}, {1, 0, 1}, {1, 1, 0}, {2, 0, 0}};
-  static constexpr int of_m(int a) { return find(ME[a][0], ME[a][1], ME[a][2]); }
-  static constexpr int of_pair(int a, int c) { return find(ME[a][0] + ME[c][0], ME[a][1] + ME[c][1], ME[a][2] + ME[c][2]); }
-  // packed upper triangle t -> (a, c), row a holds A[a][a..9]
+  static constexpr int of_m(int a) { return mom::find(mom::tab_exponent(ORDER, a, 0), mom::tab_exponent(ORDER, a, 1), mom::tab_exponent(ORDER, a, 2)); }
+  static constexpr int of_pair(int a, int c) {
+    return mom::find(mom::tab_exponent(ORDER, a, 0) + mom::tab_exponent(ORDER, c, 0), mom::tab_exponent(ORDER, a, 1) + mom::tab_exponent(ORDER, c, 1),
+                     mom::tab_exponent(ORDER, a, 2) + mom::tab_exponent(ORDER, c, 2));
+  }
+  // packed upper triangle t -> (a, c), row a holds A[a][a..J-1]
   static constexpr int row_of(int t) {
     int a = 0;
-    while (t >= 10 - a) {
-      t -= 10 - a;
+    while (t >= J - a) {
+      t -= J - a;
       ++a;
     }
     return a;
   }
   static constexpr int col_of(int t) {
     int a = 0;
-    while (t >= 10 - a) {
-      t -= 10 - a;
+    while (t >= J - a) {
+      t -= J - a;
       ++a;
     }
     return a + t;
@@ -112,20 +144,26 @@ struct Moments {
   struct M1 {
     static constexpr int mom = of_m(A);
   };
-  template <int... I>
-  __device__ __forceinline__ static void monomials(double (&mono)[N], const double (&d)[3], std::integer_sequence<int, I...>) {
+  // mono[0 .. sizeof...(I)]: the monomials in moment order, each its parent times one coordinate
+  template <int NM, int... I>
+  __device__ __forceinline__ static void monomials(double (&mono)[NM], const double (&d)[3], std::integer_sequence<int, I...>) {
     mono[0] = 1.0;
     ((mono[I + 1] = mono[C<I + 1>::par] * d[C<I + 1>::ax]), ...);
   }
   template <int... T>
-  __device__ __forceinline__ static void expand(const double (&M)[N], double (&A)[55], std::integer_sequence<int, T...>) {
+  __device__ __forceinline__ static void expand(const double (&M)[N], double (&A)[NT], std::integer_sequence<int, T...>) {
     ((A[T] = M[P<T>::mom]), ...);
   }
-  template <int... A>
-  __device__ __forceinline__ static void firsts(const double (&mono)[N], double (&m)[10], std::integer_sequence<int, A...>) {
+  template <int NM, int... A>
+  __device__ __forceinline__ static void firsts(const double (&mono)[NM], double (&m)[J], std::integer_sequence<int, A...>) {
     ((m[A] = mono[M1<A>::mom]), ...);
   }
 };
+using Moments = MomentsT<2>;
+static_assert(Moments::N == 35 && Moments::J == 10 && MomentsT<3>::N == 84 && MomentsT<3>::J == 20, "moment counts");
+static_assert(Moments::of_m(4) == mom::find(0, 1, 1) && Moments::of_m(9) == mom::find(2, 0, 0) && MomentsT<3>::of_m(19) == mom::find(3, 0, 0) &&
+                  MomentsT<3>::of_m(12) == mom::find(1, 0, 2),
+              "tabular_monomials order");
 
 struct ScatteredModel {
   const double *pts;     // [npts][8]: x, y, z, lnN[4], nearest-sample distance
@@ -230,7 +268,7 @@ struct ScatteredModel {
       m[2] = dy;
       m[3] = dx;
     }
-    if (J >= 10) {
+    if (J == 10) {
       // order 2: (0,0,0)(0,0,1)(0,0,2)(0,1,0)(0,1,1)(0,2,0)(1,0,0)(1,0,1)(1,1,0)(2,0,0)
       m[1] = dz;
       m[2] = dz * dz;
@@ -242,6 +280,136 @@ struct ScatteredModel {
       m[8] = dx * dy;
       m[9] = dx * dx;
     }
+    if constexpr (J == 20) { // order 3: the 20 monomials of degree <= 3 in the reference's (lexicographic) order
+      const double dd[3] = {dx, dy, dz};
+      double mono[20];
+      MomentsT<3>::monomials(mono, dd, std::make_integer_sequence<int, 19>{});
+      MomentsT<3>::firsts(mono, m, std::make_integer_sequence<int, 20>{});
+    }
+  }
+
+  // Normal equations of order 3 (J = 20): the 84 moments + 80 right-hand sums, then A (210 entries) is laid out in
+  // private memory and factorised by rolled loops (dposv 'U' as solve_fit): once per fit, against hundreds of folds.
+  struct Sums20 {
+    double Mm[MomentsT<3>::N], b[20][4];
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+      for (int t = 0; t < MomentsT<3>::N; ++t) Mm[t] = 0.0;
+#pragma unroll
+      for (int a = 0; a < 20; ++a)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) b[a][s] = 0.0;
+    }
+    __device__ __forceinline__ void fold(double w2, double d0, double d1, double d2, const double (&ln)[4]) {
+      using MT = MomentsT<3>;
+      const double dd[3] = {d0, d1, d2};
+      double mono[MT::N], m[20];
+      MT::monomials(mono, dd, std::make_integer_sequence<int, MT::N - 1>{});
+      Mm[0] += w2;
+#pragma unroll
+      for (int i = 1; i < MT::N; ++i) Mm[i] += w2 * mono[i];
+      MT::firsts(mono, m, std::make_integer_sequence<int, 20>{});
+#pragma unroll
+      for (int a = 0; a < 20; ++a) {
+        const double wa = w2 * m[a];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) b[a][s] += wa * ln[s];
+      }
+    }
+    template <class F>
+    __device__ __forceinline__ void reduce(F sum) {
+#pragma unroll
+      for (int t = 0; t < MomentsT<3>::N; ++t) Mm[t] = sum(Mm[t]);
+#pragma unroll
+      for (int a = 0; a < 20; ++a)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) b[a][s] = sum(b[a][s]);
+    }
+    __device__ __noinline__ int solve(double fi[4]) const {
+      using MT = MomentsT<3>;
+      constexpr int J = 20;
+      double A[MT::NT], y[J], bb[J][4]; // private memory: indexed by loop variables below
+      MT::expand(Mm, A, std::make_integer_sequence<int, MT::NT>{});
+#pragma unroll
+      for (int a = 0; a < J; ++a)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) bb[a][s] = b[a][s];
+      auto at = [&](int r, int c) -> double & { return A[r * J - r * (r - 1) / 2 + (c - r)]; };
+#pragma unroll 1
+      for (int j = 0; j < J; ++j) {
+        double s = at(j, j);
+#pragma unroll 1
+        for (int l = 0; l < j; ++l) s -= at(l, j) * at(l, j);
+        if (!(s > 0.0)) return 1;
+        const double ujj = sqrt(s), inv = 1.0 / ujj;
+        at(j, j) = ujj;
+#pragma unroll 1
+        for (int c = j + 1; c < J; ++c) {
+          double t = at(j, c);
+#pragma unroll 1
+          for (int l = 0; l < j; ++l) t -= at(l, c) * at(l, j);
+          at(j, c) = t * inv;
+        }
+      }
+#pragma unroll 1
+      for (int i = 0; i < J; ++i) { // U^T z = e_1
+        double t = (i == 0) ? 1.0 : 0.0;
+#pragma unroll 1
+        for (int l = 0; l < i; ++l) t -= at(l, i) * y[l];
+        y[i] = t / at(i, i);
+      }
+#pragma unroll 1
+      for (int i = J - 1; i >= 0; --i) { // U y = z
+        double t = y[i];
+#pragma unroll 1
+        for (int l = i + 1; l < J; ++l) t -= at(i, l) * y[l];
+        y[i] = t / at(i, i);
+      }
+      double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 1
+      for (int j = 0; j < J; ++j)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[s] += y[j] * bb[j][s];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) fi[s] = acc[s];
+      return 0;
+    }
+  };
+
+  // order 3 (J = 20) per lane: as interpolate<J> below, with the moments standing in for A
+  __device__ __noinline__ int interpolate_o3(const double x[3], double fi[4]) const {
+    constexpr int J = 20;
+    int count = 0;
+    double sw = 0.0, swv = 0.0;
+    for_neighbours(x, [&](const double *q, double, double, double, double r) {
+      double cw = 0.5 + 0.5 * cos(r * 2.0 * PI / radius / 2.0);
+      sw += cw;
+      swv += cw * q[7];
+      ++count;
+    });
+    fi[0] = fi[1] = fi[2] = fi[3] = 0.0;
+    if (count < J) return 2;
+    const double hin = lws * (swv / sw);
+    Sums20 S;
+    int kept = 0;
+    bool usemask = true;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      S.zero();
+      kept = 0;
+      for_neighbours(x, [&](const double *q, double d0, double d1, double d2, double r) {
+        double e = etainv(r, hin);
+        if (usemask && !(e > 1.0e-16)) return; // :316-317
+        ++kept;
+        const double ln[4] = {q[3], q[4], q[5], q[6]};
+        S.fold(0.5 * e, d0, d1, d2, ln);
+      });
+      if (kept >= J) break;
+      usemask = false; // threw out too many samples: use them all (:319-323)
+    }
+    double f4[4];
+    if (S.solve(f4) != 0) return 1;
+    fi[0] = f4[0], fi[1] = f4[1], fi[2] = f4[2], fi[3] = f4[3];
+    return 0;
   }
 
   // returns status: 0 ok, 1 solve failed, 2 too few samples (lsinterp_mod.f95:262-264)
@@ -679,8 +847,10 @@ struct ScatteredModel {
     SRT_PHASE(3);
     // ---- pass 2: normal equations.  Group g walks the records for point g, its 8 lanes splitting them; no
     // transcendental function and no branch in the loop
-    double A[NT], b[J][4];
+    constexpr bool O3 = J == 20; // order 3: all sums live in S20 (84 moments + 80), A is only formed inside its solve
+    double A[O3 ? 1 : NT], b[O3 ? 1 : J][4];
     double Mm[J == 10 ? Moments::N : 1]; // order 2: the 35 moments stand in for the 55 entries of A while summing
+    typename std::conditional<O3, Sums20, int>::type S20;
     int kept = 0;
     bool usemask = true, todo = fit;
     const double eta1 = 1.0 + eta;
@@ -690,19 +860,22 @@ struct ScatteredModel {
     for (int attempt = 0; attempt < 2; ++attempt) {
       if (!__any(todo)) break; // wave-uniform
       if (todo) {
+        if constexpr (O3) S20.zero();
 #pragma unroll
-        for (int t = 0; t < NT; ++t) A[t] = 0.0;
+        for (int t = 0; t < (O3 ? 1 : NT); ++t) A[t] = 0.0;
 #pragma unroll
         for (int t = 0; t < (J == 10 ? Moments::N : 1); ++t) Mm[t] = 0.0;
 #pragma unroll
-        for (int a = 0; a < J; ++a)
+        for (int a = 0; a < (O3 ? 1 : J); ++a)
 #pragma unroll
           for (int s = 0; s < 4; ++s) b[a][s] = 0.0;
         kept = 0;
       }
       double pw2 = 0.0, pd0 = 0.0, pd1 = 0.0, pd2 = 0.0, pln[4] = {0.0, 0.0, 0.0, 0.0}; // the record waiting to be folded in
       auto fold = [&](double w2, double d0, double d1, double d2, const double (&ln)[4]) {
-        if constexpr (J == 10) {
+        if constexpr (O3) {
+          S20.fold(w2, d0, d1, d2, ln);
+        } else if constexpr (J == 10) {
           const double dd[3] = {d0, d1, d2};
           double mono[Moments::N], m[10];
           Moments::monomials(mono, dd, std::make_integer_sequence<int, Moments::N - 1>{});
@@ -823,23 +996,34 @@ struct ScatteredModel {
     // combine the 8 lanes' partial sums and solve
     fi.v[0] = fi.v[1] = fi.v[2] = fi.v[3] = 0.0;
     if (__any(fit)) {
-      if constexpr (J == 10) {
+      if constexpr (O3) {
+        S20.reduce([](double v) { return group_sum(v); });
+        if (fit) {
+          double f4[4];
+          if (S20.solve(f4) == 0) {
 #pragma unroll
-        for (int t = 0; t < Moments::N; ++t) Mm[t] = group_sum(Mm[t]);
-        Moments::expand(Mm, A, std::make_integer_sequence<int, 55>{});
+            for (int s = 0; s < 4; ++s) fi.v[s] = f4[s];
+          }
+        }
       } else {
+        if constexpr (J == 10) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) A[t] = group_sum(A[t]);
-      }
+          for (int t = 0; t < Moments::N; ++t) Mm[t] = group_sum(Mm[t]);
+          Moments::expand(Mm, A, std::make_integer_sequence<int, 55>{});
+        } else {
 #pragma unroll
-      for (int a = 0; a < J; ++a)
+          for (int t = 0; t < NT; ++t) A[t] = group_sum(A[t]);
+        }
 #pragma unroll
-        for (int s = 0; s < 4; ++s) b[a][s] = group_sum(b[a][s]);
-      if (fit) {
-        double f4[4];
-        if (solve_fit<J>(A, b, f4) == 0) {
+        for (int a = 0; a < J; ++a)
 #pragma unroll
-          for (int s = 0; s < 4; ++s) fi.v[s] = f4[s];
+          for (int s = 0; s < 4; ++s) b[a][s] = group_sum(b[a][s]);
+        if (fit) {
+          double f4[4];
+          if (solve_fit<J>(A, b, f4) == 0) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) fi.v[s] = f4[s];
+          }
         }
       }
     }
@@ -879,7 +1063,9 @@ struct ScatteredModel {
     const bool fit = live && count >= J; // else status 2: too few samples (lsinterp_mod.f95:262-264)
     const double hin = lws * (swv / sw);
     // ---- pass 2: normal equations
-    double A[NT], b[J][4];
+    constexpr bool O3 = J == 20; // order 3: all sums live in S20 (84 moments + 80), A is only formed inside its solve
+    double A[O3 ? 1 : NT], b[O3 ? 1 : J][4];
+    typename std::conditional<O3, Sums20, int>::type S20;
     int kept = 0;
     bool usemask = true, todo = fit;
     auto body2q = [&](const double (&q)[8]) {
@@ -889,16 +1075,21 @@ struct ScatteredModel {
       if (usemask && !(e > 1.0e-16)) return; // :316-317
       ++kept;
       double w2 = 0.5 * e;
-      double m[J];
-      monomials<J>(d0, d1, d2, m);
-      int t = 0;
+      if constexpr (O3) {
+        const double ln[4] = {q[3], q[4], q[5], q[6]};
+        S20.fold(w2, d0, d1, d2, ln);
+      } else {
+        double m[J];
+        monomials<J>(d0, d1, d2, m);
+        int t = 0;
 #pragma unroll
-      for (int a = 0; a < J; ++a) {
-        double wa = w2 * m[a];
+        for (int a = 0; a < J; ++a) {
+          double wa = w2 * m[a];
 #pragma unroll
-        for (int cI = a; cI < J; ++cI) A[t++] += wa * m[cI];
+          for (int cI = a; cI < J; ++cI) A[t++] += wa * m[cI];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) b[a][s] += wa * q[3 + s];
+          for (int s = 0; s < 4; ++s) b[a][s] += wa * q[3 + s];
+        }
       }
     };
     auto guarded = [&](int i) {
@@ -914,10 +1105,11 @@ struct ScatteredModel {
     for (int attempt = 0; attempt < 2; ++attempt) {
       if (!__any(todo)) break; // wave-uniform
       if (todo) {
+        if constexpr (O3) S20.zero();
 #pragma unroll
-        for (int t = 0; t < NT; ++t) A[t] = 0.0;
+        for (int t = 0; t < (O3 ? 1 : NT); ++t) A[t] = 0.0;
 #pragma unroll
-        for (int a = 0; a < J; ++a)
+        for (int a = 0; a < (O3 ? 1 : J); ++a)
 #pragma unroll
           for (int s = 0; s < 4; ++s) b[a][s] = 0.0;
         kept = 0;
@@ -934,17 +1126,28 @@ struct ScatteredModel {
     // combine the 8 lanes' partial sums and solve
     fi.v[0] = fi.v[1] = fi.v[2] = fi.v[3] = 0.0;
     if (__any(fit)) {
+      if constexpr (O3) {
+        S20.reduce([](double v) { return group_sum(v); });
+        if (fit) {
+          double f4[4];
+          if (S20.solve(f4) == 0) {
 #pragma unroll
-      for (int t = 0; t < NT; ++t) A[t] = group_sum(A[t]);
+            for (int s = 0; s < 4; ++s) fi.v[s] = f4[s];
+          }
+        }
+      } else {
 #pragma unroll
-      for (int a = 0; a < J; ++a)
+        for (int t = 0; t < NT; ++t) A[t] = group_sum(A[t]);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) b[a][s] = group_sum(b[a][s]);
-      if (fit) {
-        double f4[4];
-        if (solve_fit<J>(A, b, f4) == 0) {
+        for (int a = 0; a < J; ++a)
 #pragma unroll
-          for (int s = 0; s < 4; ++s) fi.v[s] = f4[s];
+          for (int s = 0; s < 4; ++s) b[a][s] = group_sum(b[a][s]);
+        if (fit) {
+          double f4[4];
+          if (solve_fit<J>(A, b, f4) == 0) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) fi.v[s] = f4[s];
+          }
         }
       }
     }
@@ -1133,7 +1336,8 @@ struct ScatteredModel {
       double fi[4];
       if (order == 0) interpolate<1>(x, fi);
       else if (order == 1) interpolate<4>(x, fi);
-      else interpolate<10>(x, fi);
+      else if (order == 2) interpolate<10>(x, fi);
+      else interpolate_o3(x, fi);
 #pragma unroll
       for (int s = 0; s < 4; ++s) Ns[s] = (s < nspec) ? exp(fi[s]) : 0.0; // failed fit: fi = 0 -> Ns = 1
     } else {
@@ -1155,7 +1359,8 @@ struct ScatteredModel {
       SRT_LDS int *lists = (SRT_LDS int *)lds;
       if (order == 0) coop_stencil<1>(cc, dd, ee, 7 + NE, need, out, lists);
       else if (order == 1) coop_stencil<4>(cc, dd, ee, 7 + NE, need, out, lists);
-      else coop_stencil<10>(cc, dd, ee, 7 + NE, need, out, lists);
+      else if (order == 2) coop_stencil<10>(cc, dd, ee, 7 + NE, need, out, lists);
+      else coop_stencil<20>(cc, dd, ee, 7 + NE, need, out, lists);
 #pragma unroll
       for (int i = 0; i < 7 + NE; ++i)
 #pragma unroll

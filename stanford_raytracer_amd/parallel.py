@@ -1,11 +1,22 @@
 """Multi-GPU layer: rays are independent, so the launch set is cut into contiguous shards (one per rank,
 one rank per GPU, one model replica per rank) and the only communication is the final gather of the
-trajectory buffers to rank 0 (RCCL over xGMI with backend "nccl"; "gloo" on CPU for tests).
+trajectory rows to rank 0 (RCCL over xGMI with backend "nccl"; "gloo" on CPU for tests).
 
 The reference has no parallel mode at all (serial `do` over rays, raytracer_driver.f95:1144-1232);
 shards reproduce exactly what running it on disjoint ray files would.
+
+The gather is variable-length: a ray keeps (nrows-1)/outputper + 1 of its slots, so every
+rank packs its kept rows back to back (srt_pack_rows_device on the GPU), the ranks exchange their counts
+(one all_gather of two int64 per rank), and every peer sends exactly its packed rows, nrows and stop codes
+to the root in ONE group of point-to-point transfers (RCCL has no gatherv; 7 concurrent transfers use the 7
+xGMI links into the root).  bench.py --gpus N, the 2-rank GPU test and the gloo CPU test all run
+`trace_sharded` below -- there is no second implementation.
 """
+import time
+
 import numpy as np
+
+ROW = 20
 
 
 def shard_bounds(nrays, rank, world):
@@ -16,32 +27,129 @@ def shard_bounds(nrays, rank, world):
     return lo, hi
 
 
-def gather_to_root(dist, local, per, dst=0):
-    """Gather a per-ray tensor [n_local, ...] from every rank to `dst`, padded to `per` rows per rank.
+def kept_rows(nrows, outputper, slots):
+    """Rows of a ray that exist in its slots: 0, outputper, 2*outputper, .. < nrows (torch or numpy)."""
+    k = (nrows - 1) // outputper + 1
+    k = k * (nrows > 0)
+    return k.clip(0, slots) if isinstance(k, np.ndarray) else k.clamp(0, slots)
 
-    Returns the stacked [world*per, ...] tensor on dst (caller trims to nrays), None elsewhere."""
+
+def pack_rows_torch(rows, nrows, outputper):
+    """Reference packer in plain torch (what srt_pack_rows_device does on the GPU): rows[n,slots,20], nrows[n]
+    -> (packed[total,20], offsets[n+1] int64).  Used by the CPU tests and to cross-check the HIP packer."""
+    import torch
+
+    n, slots = rows.shape[0], rows.shape[1]
+    kept = kept_rows(nrows.to(torch.int64), outputper, slots)
+    offsets = torch.zeros(n + 1, dtype=torch.int64, device=rows.device)
+    if n:
+        offsets[1:] = torch.cumsum(kept, 0)
+        mask = torch.arange(slots, device=rows.device)[None, :] < kept[:, None]
+        packed = rows[mask]
+    else:
+        packed = rows.reshape(0, ROW)
+    return packed.contiguous(), offsets
+
+
+def pack_rows_device(rows, nrows, outputper, stream=None):
+    """srt_pack_rows_device on torch CUDA tensors -> (packed[total,20] (a view of a worst-case buffer), offsets[n+1])."""
+    import torch
+
+    from . import api
+
+    n, slots = rows.shape[0], rows.shape[1]
+    offsets = torch.empty(n + 1, dtype=torch.int64, device=rows.device)
+    packed = torch.empty((max(n * slots, 1), ROW), dtype=torch.float64, device=rows.device)
+    st = stream if stream is not None else torch.cuda.current_stream(rows.device)
+    api._check(api.lib().srt_pack_rows_device(slots, outputper, n, rows.data_ptr(), nrows.data_ptr(), offsets.data_ptr(),
+                                              packed.data_ptr(), n * slots, st.cuda_stream))
+    total = int(offsets[n].item())  # synchronises the stream
+    return packed[:total], offsets
+
+
+def _sync(t):
+    if t.is_cuda:
+        import torch
+
+        torch.cuda.synchronize(t.device)
+
+
+def gather_packed(dist, packed, nrows, stop, nrays, dst=0):
+    """Variable-length gather to `dst`: every rank contributes packed[total_r,20], nrows[n_r], stop[n_r] of its
+    contiguous shard.  Returns (packed_all[total,20], nrows_all[nrays], stop_all[nrays], bytes_received) on dst, None
+    elsewhere.  gloo cannot move device memory: there the buffers are staged through the host."""
     import torch
 
     world, rank = dist.get_world_size(), dist.get_rank()
-    if local.shape[0] < per:
-        pad = torch.zeros((per - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-        local = torch.cat([local, pad], dim=0)
-    local = local.contiguous()
-    bufs = [torch.empty_like(local) for _ in range(world)] if rank == dst else None
-    dist.gather(local, bufs, dst=dst)
+    dev = packed.device
+    stage = dist.get_backend() == "gloo" and packed.is_cuda
+    cdev = torch.device("cpu") if stage else dev
+    # 1. counts: [rays, kept rows] of every rank
+    mine = torch.tensor([nrows.shape[0], packed.shape[0]], dtype=torch.int64, device=cdev)
+    allc = [torch.zeros(2, dtype=torch.int64, device=cdev) for _ in range(world)]
+    dist.all_gather(allc, mine)
+    counts = torch.stack(allc).cpu().numpy()
+    nray_r, nrow_r = counts[:, 0], counts[:, 1]
+    if int(nray_r.sum()) != nrays:
+        raise RuntimeError("shards cover %d rays, expected %d" % (int(nray_r.sum()), nrays))
+    ray0 = np.concatenate([[0], np.cumsum(nray_r)])
+    row0 = np.concatenate([[0], np.cumsum(nrow_r)])
+    src = [t.cpu() if stage else t for t in (packed.contiguous(), nrows.contiguous(), stop.contiguous())]
+    ops = []
+    out = None
+    if rank == dst:
+        out = (torch.empty((int(row0[-1]), ROW), dtype=packed.dtype, device=cdev),
+               torch.empty(nrays, dtype=nrows.dtype, device=cdev), torch.empty(nrays, dtype=stop.dtype, device=cdev))
+        for r in range(world):
+            sl = [out[0][row0[r]:row0[r + 1]], out[1][ray0[r]:ray0[r + 1]], out[2][ray0[r]:ray0[r + 1]]]
+            if r == dst:
+                for d, s in zip(sl, src):
+                    d.copy_(s)
+            else:
+                ops += [dist.P2POp(dist.irecv, t, r) for t in sl if t.numel()]
+    else:
+        ops += [dist.P2POp(dist.isend, t, dst) for t in src if t.numel()]
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
     if rank != dst:
         return None
-    return torch.cat(bufs, dim=0)
+    recv = int((row0[-1] - nrow_r[dst]) * ROW * 8 + (nrays - nray_r[dst]) * 8)
+    if stage:
+        out = tuple(t.to(dev) for t in out)
+    return out + (recv,)
 
 
-def trace_sharded(dist, nrays, trace_fn, dst=0):
-    """Run trace_fn(lo, hi) -> (rows[n,slots,20], nrows[n], stop[n]) (torch tensors) on this rank's shard
-    and gather everything to rank `dst` in ray order.  Returns (rows, nrows, stop) on dst, else None."""
+def trace_sharded(dist, nrays, trace_fn, pack_fn, dst=0, timings=None):
+    """Run trace_fn(lo, hi) -> (rows[n,slots,20], nrows[n], stop[n]) (torch tensors) on this rank's shard, pack the
+    kept rows with pack_fn(rows, nrows) -> (packed, offsets) and gather them to rank `dst` in ray order.
+    Returns (packed_all, nrows_all, stop_all) on dst, else None.  timings (dict, optional) receives this rank's
+    trace_s, pack_s, gather_s (each closed by a device synchronisation) and gather_bytes on dst."""
     world, rank = dist.get_world_size(), dist.get_rank()
     lo, hi = shard_bounds(nrays, rank, world)
+    t0 = time.perf_counter()
     rows, nrows, stop = trace_fn(lo, hi)
-    per = (nrays + world - 1) // world
-    out = [gather_to_root(dist, t, per, dst) for t in (rows, nrows, stop)]
-    if rank != dst:
-        return None
-    return tuple(t[:nrays] for t in out)
+    _sync(rows)
+    t1 = time.perf_counter()
+    packed, _ = pack_fn(rows, nrows)
+    _sync(packed)
+    t2 = time.perf_counter()
+    res = gather_packed(dist, packed, nrows, stop, nrays, dst)
+    _sync(packed)
+    t3 = time.perf_counter()
+    if timings is not None:
+        timings.update(trace_s=t1 - t0, pack_s=t2 - t1, gather_s=t3 - t2, gather_bytes=res[3] if res is not None else 0,
+                       shard=(lo, hi))
+    return None if res is None else res[:3]
+
+
+def unpack_rows(packed, nrows, outputper, slots):
+    """Inverse of the packing on the root: -> rows[n, slots, 20] (zero beyond a ray's kept rows)."""
+    import torch
+
+    n = nrows.shape[0]
+    kept = kept_rows(nrows.to(torch.int64), outputper, slots)
+    rows = torch.zeros((n, slots, ROW), dtype=packed.dtype, device=packed.device)
+    mask = torch.arange(slots, device=packed.device)[None, :] < kept[:, None]
+    rows[mask] = packed
+    return rows

@@ -1,4 +1,7 @@
-"""CPU, world_size 2, gloo: the N>1 path (shard -> trace -> gather to rank 0) with a stand-in trace."""
+"""CPU, world_size 2, gloo: the N>1 path -- shard -> trace -> pack -> variable-length gather to rank 0 -- through
+parallel.trace_sharded, the one implementation bench.py --gpus N and tests/test_gpu_multirank.py also run.  Here
+the trace is a stand-in with ragged row counts and the packer is the plain-torch reference (the HIP packer needs a
+GPU); everything else is the product code."""
 import os
 import socket
 
@@ -8,6 +11,8 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from stanford_raytracer_amd import parallel
+
+SLOTS, OUTPUTPER = 4, 3
 
 
 def test_shard_bounds_cover_everything():
@@ -20,23 +25,48 @@ def test_shard_bounds_cover_everything():
             assert max(hi - lo for lo, hi in spans) <= (n + world - 1) // world
 
 
-def _fake_trace(lo, hi, slots=3):
+def _fake_trace(lo, hi):
     idx = torch.arange(lo, hi, dtype=torch.float64)
-    rows = idx[:, None, None] + torch.arange(slots * 20, dtype=torch.float64).reshape(1, slots, 20) * 1e-3
-    nrows = (idx % 5 + 1).to(torch.int32)
+    rows = idx[:, None, None] + torch.arange(SLOTS * 20, dtype=torch.float64).reshape(1, SLOTS, 20) * 1e-3
+    nrows = (idx % (SLOTS * OUTPUTPER) + 1).to(torch.int32)  # 1 .. maxsteps rows: 1 .. SLOTS kept
+    nrows[(idx % 7) == 3] = 0  # a ray that produced nothing keeps nothing
     stop = (idx % 3).to(torch.int32)
     return rows, nrows, stop
+
+
+def _pack(rows, nrows):
+    return parallel.pack_rows_torch(rows, nrows, OUTPUTPER)
+
+
+def test_pack_unpack_roundtrip():
+    rows, nrows, _ = _fake_trace(0, 50)
+    packed, off = _pack(rows, nrows)
+    kept = parallel.kept_rows(nrows.to(torch.int64), OUTPUTPER, SLOTS)
+    assert off[-1] == kept.sum() == packed.shape[0]
+    back = parallel.unpack_rows(packed, nrows, OUTPUTPER, SLOTS)
+    mask = torch.arange(SLOTS)[None, :] < kept[:, None]
+    assert torch.equal(back[mask], rows[mask]) and float(back[~mask].abs().sum()) == 0.0
+    # ray i's rows sit at offsets[i] .. offsets[i+1]
+    for i in (0, 3, 17, 49):
+        assert torch.equal(packed[off[i]:off[i + 1]], rows[i, :kept[i]])
 
 
 def _worker(rank, world, port, nrays, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    out = parallel.trace_sharded(dist, nrays, _fake_trace, dst=0)
+    tm = {}
+    out = parallel.trace_sharded(dist, nrays, _fake_trace, _pack, dst=0, timings=tm)
+    assert tm["shard"] == parallel.shard_bounds(nrays, rank, world)
     if rank == 0:
-        rows, nrows, stop = out
+        packed, nrows, stop = out
         er, en, es = _fake_trace(0, nrays)
-        q.put(bool(torch.equal(rows, er) and torch.equal(nrows, en) and torch.equal(stop, es)))
+        ep, _ = _pack(er, en)
+        lo, hi = parallel.shard_bounds(nrays, 0, world)
+        own = int(parallel.kept_rows(en[lo:hi].to(torch.int64), OUTPUTPER, SLOTS).sum())
+        expect_bytes = (ep.shape[0] - own) * 160 + (nrays - (hi - lo)) * 8
+        q.put(bool(torch.equal(packed, ep) and torch.equal(nrows, en) and torch.equal(stop, es)
+                   and tm["gather_bytes"] == expect_bytes))
     else:
         assert out is None
     dist.barrier()
@@ -52,7 +82,7 @@ def _free_port():
 
 
 def test_gather_world2_gloo():
-    for nrays in (11, 8, 1):  # ragged last shard, even split, fewer rays than ranks
+    for nrays in (11, 8, 1):  # ragged last shard, even split, fewer rays than ranks (rank 1 sends nothing)
         ctx = mp.get_context("spawn")
         q = ctx.Queue()
         port = _free_port()

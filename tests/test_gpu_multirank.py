@@ -1,0 +1,123 @@
+"""The N>1 path with the REAL kernel: 2 ranks (gloo rendezvous, both on cuda:0 -- the GPU box has one card and RCCL
+refuses two ranks on one device) each trace their contiguous shard of one launch set with srt_trace_batch_device,
+pack the kept rows with srt_pack_rows_device and gather them to rank 0 through parallel.trace_sharded -- the code
+bench.py --gpus N runs.  The gathered rows must be bit-identical to a single-rank trace of the whole set
+(rays are independent: raytracer_driver.f95:1144-1232 is a serial loop with no carried state)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+NRAYS, GRID, OUTPUTPER, MAXSTEPS = 3001, 24, 4, 96  # ragged: shards of 1501 and 1500 rays
+
+
+def _setup(lo, hi):
+    import torch
+
+    from stanford_raytracer_amd import api, workloads as wl
+    from stanford_raytracer_amd.device_batch import DeviceBatch
+
+    api.init(0)
+    dev = torch.device("cuda", 0)
+    F, b = wl.make_grid(GRID, half_width=10.0 * wl.R_E)
+    model = api.Model.interp(F, b, wl.QS, wl.MS)
+    p = api.make_params(fixedstep=0, dt0=1e-3, dtmax=0.1, maxerr=5e-4, tmax=0.5, root=2, minalt=wl.MINALT,
+                        maxsteps=MAXSTEPS, outputper=OUTPUTPER, del_=1e-6, ray_order=1)
+    pos0, dir0, w0 = wl.launch_set(NRAYS, 4)
+    return model, p, DeviceBatch(model, p, pos0[lo:hi], dir0[lo:hi], w0[lo:hi], dev)
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+
+    from stanford_raytracer_amd import parallel
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = parallel.shard_bounds(NRAYS, rank, world)
+    model, p, batch = _setup(lo, hi)
+    tm = {}
+    out = parallel.trace_sharded(dist, NRAYS, lambda a, b: batch.trace(),
+                                 lambda rows, nrows: parallel.pack_rows_device(rows, nrows, OUTPUTPER), dst=0, timings=tm)
+    if rank == 0:
+        packed, nrows, stop = out
+        q.put((packed.cpu().numpy(), nrows.cpu().numpy(), stop.cpu().numpy(), tm["gather_bytes"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_rank_gather_is_bit_identical_to_one_rank():
+    import torch
+    import torch.multiprocessing as mp
+
+    from stanford_raytracer_amd import parallel
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    packed2, nrows2, stop2, nbytes = q.get(timeout=300)
+    for pr in procs:
+        pr.join(120)
+        assert pr.exitcode == 0
+    # single rank, whole set, same library
+    model, p, batch = _setup(0, NRAYS)
+    rows, nrows, stop = batch.trace()
+    torch.cuda.synchronize()
+    packed1, off = parallel.pack_rows_device(rows, nrows, OUTPUTPER)
+    pt, offt = parallel.pack_rows_torch(rows, nrows, OUTPUTPER)  # the HIP packer against the plain-torch one
+    assert torch.equal(off, offt) and torch.equal(packed1, pt)
+    assert np.array_equal(nrows2, nrows.cpu().numpy()) and np.array_equal(stop2, stop.cpu().numpy())
+    assert packed2.shape == tuple(packed1.shape)
+    assert np.array_equal(packed2.view(np.uint64), packed1.cpu().numpy().view(np.uint64)), "gathered rows differ bitwise"
+    lo, hi = parallel.shard_bounds(NRAYS, 0, 2)
+    assert nbytes == int(off[-1] - off[hi]) * 160 + (NRAYS - hi) * 8
+    assert int(off[-1]) < NRAYS * batch.slots  # the gather moved fewer rows than the padded buffer holds
+    assert nrows.max() > 1
+
+
+def test_pack_rows_edge_cases():
+    """srt_pack_rows_device: zero rays, zero kept rows, a capacity that is too small."""
+    import ctypes as C
+
+    import torch
+
+    from stanford_raytracer_amd import api, parallel
+
+    api.init(0)
+    dev = torch.device("cuda", 0)
+    slots, per = 5, 3
+    nrows = torch.tensor([0, 1, 3, 4, 15, 16, 200], dtype=torch.int32, device=dev)  # 200: clamped to the slots
+    rows = torch.arange(7 * slots * 20, dtype=torch.float64, device=dev).reshape(7, slots, 20)
+    packed, off = parallel.pack_rows_device(rows, nrows, per)
+    assert off.cpu().tolist() == [0, 0, 1, 2, 4, 9, 14, 19]
+    pt, offt = parallel.pack_rows_torch(rows, nrows, per)
+    assert torch.equal(off, offt) and torch.equal(packed, pt)
+    e = torch.zeros((0, slots, 20), dtype=torch.float64, device=dev)
+    packed, off = parallel.pack_rows_device(e, torch.zeros(0, dtype=torch.int32, device=dev), per)
+    assert packed.shape[0] == 0 and off.cpu().tolist() == [0]
+    # capacity 3 rows: rays 0..2 fit, the total still reports 19
+    offs = torch.empty(8, dtype=torch.int64, device=dev)
+    small = torch.full((3, 20), -1.0, dtype=torch.float64, device=dev)
+    api._check(api.lib().srt_pack_rows_device(slots, per, 7, rows.data_ptr(), nrows.data_ptr(), offs.data_ptr(),
+                                              small.data_ptr(), 3, None))
+    torch.cuda.synchronize()
+    assert int(offs[7]) == 19 and torch.equal(small[:2], pt[:2]) and float(small[2, 0]) == -1.0

@@ -141,23 +141,62 @@ def test_layered_entry_points_handle_ragged_sizes(gpu_models, oracle_models):
 
 
 # ---- modelnum 4: scattered samples, moving least squares (uniform-grid neighbour search on the device) ----------
+@pytest.fixture(scope="module")
+def scat_o3():
+    import os
+
+    from conftest import GOLDEN_DIR
+    return np.load(os.path.join(GOLDEN_DIR, "scattered_o3_golden.npz"))
+
+
 @pytest.mark.parametrize("key,kw", [("g0_scattered_out", {}), ("g0_scattered_o1_out", {"order": 1}),
-                                    ("g0_scattered_exact_out", {"exact": 1, "local_window_scale": 2.0})])
-def test_g0_scattered_params(golden, pointsfile, key, kw):
+                                    ("g0_scattered_exact_out", {"exact": 1, "local_window_scale": 2.0}),
+                                    ("g0_o3_out", {"order": 3})])
+def test_g0_scattered_params(golden, scat_o3, pointsfile, key, kw):
+    """funcPlasmaParams of modelnum 4 against the reference's own outputs, orders 1, 2, 3 and the exact window.
+    The reference stores a ZERO nearest-sample distance for the one sample at the root of its kd-tree (its
+    kdtree_nearest starts from the root; which sample that is comes from the compiler's RNG).  That sample is known
+    (ref_harness --mode=scatroot -> ref_root_point): exactly the lookups whose search window holds it are perturbed
+    by the quirk (the CPU test shows the oracle reproduces them once the quirk is put in); the HIP path stores the
+    true distance, so those lookups are held against the oracle with true distances instead."""
+    from oracle import oracle
     from stanford_raytracer_amd import api
 
     m = api.Model.scattered_file(pointsfile, **kw)
-    x, ref = golden["g0_scattered_x"], golden[key]
+    x, ref = golden["g0_scattered_x"], (scat_o3[key] if key == "g0_o3_out" else golden[key])
     g = m.plasma_params(x)
     assert np.array_equal(g[:, 0:4], ref[:, 0:4]) and np.array_equal(g[:, 8:12], ref[:, 8:12])
     assert vrel(g[:, 16:19], ref[:, 16:19]).max() <= 2e-7
     assert np.array_equal(g[-5:-3, 4:8], np.zeros((2, 4)))   # inside the Earth
     assert np.array_equal(g[-2:, 4:8], np.ones((2, 4)))      # too few neighbours -> exp(0)
     ok = ref[:, 4] > 0
-    e = np.abs(g[ok, 4:8] - ref[ok, 4:8]) / ref[ok, 4:8]
-    # summation order differs from the reference's RNG-dependent one; the reference also stores a zero spacing
-    # for the one sample that is its tree root, which perturbs the few lookups near it
-    assert np.percentile(e, 97) <= 1e-9 and e.max() <= 1e-2
+    radius = float(scat_o3["ref_maxnearest"]) * 1.5           # maxnearest * window_scale
+    near = np.linalg.norm(x - scat_o3["ref_root_point"], axis=1) < radius
+    assert 0 < near.sum() < 10
+    far = ok & ~near
+    e = np.abs(g[far, 4:8] - ref[far, 4:8]) / ref[far, 4:8]
+    assert e.max() <= 1e-9, e.max()                           # summation order only
+    o = oracle.Model.scattered_file(pointsfile, perm_seed=2 | 0x80000000, **kw)   # true distance for every sample
+    on = np.array([np.concatenate(o.plasma_params(p)) for p in x[near]])
+    assert (np.abs(g[near, 4:8] - on[:, 4:8]) / on[:, 4:8]).max() <= 1e-9
+
+
+def test_g2_scattered_order3_gradients(scat_o3, pointsfile):
+    """The cooperative stencil path with the J = 20 fit (shared_fit<20>: 84 moments + 80 sums, lsinterp_mod.f95:91-99)
+    against the reference's own dFdk, dFdw, dFdx; and the own-list path (SRT_SCATTERED_STAGING=0 is covered in
+    tests/test_gpu_scattered_paths.py)."""
+    from stanford_raytracer_amd import api
+
+    m = api.Model.scattered_file(pointsfile, order=3)
+    gin, ref = scat_o3["g2_o3_in"], scat_o3["g2_o3_out"]
+    radius = float(scat_o3["ref_maxnearest"]) * 1.5
+    far = np.linalg.norm(gin[:, 0:3] - scat_o3["ref_root_point"], axis=1) >= radius
+    g = m.gradients(gin[:, 0:3], gin[:, 3:6], gin[:, 6], 1e-6)
+    assert far.sum() >= 50
+    assert vrel(g[far, 0:3], ref[far, 0:3]).max() <= 1e-7
+    assert (np.abs(g[far, 3] - ref[far, 3]) / np.abs(ref[far, 3])).max() <= 1e-6
+    ex = vrel(g[far, 4:7], ref[far, 4:7])   # d(ln N) over a 10 m stencil: 1e-13 / 1e-6 amplification
+    assert np.median(ex) <= 1e-5 and np.percentile(ex, 90) <= 1e-3
 
 
 def test_scattered_vs_oracle_ladder(gpu_models, oracle_scattered):

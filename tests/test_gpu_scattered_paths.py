@@ -153,3 +153,38 @@ def test_paths_agree_on_the_full_size_sample_set(tmp_path):
     assert np.mean(sa == sb) >= 0.97
     both = (na > 1) & (nb > 1)
     assert vrel(ra[both, 0, 16:20], rb[both, 0, 16:20]).max() <= 1e-11
+
+
+def test_order3_both_paths_and_a_short_trace(pointsfile):
+    """--scattered_interp_order=3 (J = 20: tabular_monomials to degree 3, lsinterp_mod.f95:91-99, 244-273): the shared
+    path (84 moments + 80 sums per lane, 20 x 20 Cholesky in private memory), the own-list path and the CPU oracle on
+    the same stencils, then whole adaptive trajectories against the oracle."""
+    from oracle import oracle
+    from stanford_raytracer_amd import api, workloads as wl
+
+    g = api.Model.scattered_file(pointsfile, order=3)
+    o = oracle.Model.scattered_file(pointsfile, perm_seed=2 | 0x80000000, order=3)
+    x, k, w = _states(o, 300, 1234)
+    x, k, w = x[:100], k[:100], w[:100]
+    a = g.gradients(x, k, w, 1e-6)
+    b = _own_list(lambda: g.gradients(x, k, w, 1e-6))
+    og = np.array([o.grad(p, kk, ww, 1e-6) for p, kk, ww in zip(x, k, w)])
+    assert np.isfinite(a).all() and np.isfinite(b).all()
+    assert vrel(a[:, 0:3], og[:, 0:3]).max() <= 1e-7 and vrel(a[:, 0:3], b[:, 0:3]).max() <= 1e-9
+    for other in (b, og):
+        e = vrel(a[:, 4:7], other[:, 4:7])
+        assert np.median(e) <= 1e-5 and np.percentile(e, 90) <= 1e-3
+    # trajectories: launch rows identical, fates and lengths as for order 2 (tests/test_gpu_parity.py)
+    pos, d, ww = wl.launch_set(64, 515)
+    pos = pos * 0.9
+    kw = dict(fixedstep=0, dt0=1e-3, dtmax=0.1, tmax=0.01, maxerr=5e-4, maxsteps=60, del_=1e-6)
+    rows, nrows, stop, _ = g.trace(pos, d, ww, outputper=1, **kw)
+    orows, onrows, ostop, _ = o.trace(pos, d, ww, capacity=60, **kw)
+    both = (nrows > 1) & (onrows > 1)
+    assert both.sum() >= 32
+    assert np.array_equal(rows[both, 0, 1:4], orows[both, 0, 1:4])
+    e = np.abs(rows[both, 0, 16:20] - orows[both, 0, 16:20]) / orows[both, 0, 16:20]
+    assert e.max() <= 1e-9
+    assert np.mean(stop == ostop) >= 0.9
+    assert np.median(vrel(rows[both, 1, 1:4], orows[both, 1, 1:4])) <= 1e-6
+    assert abs(int(nrows.sum()) - int(onrows.sum())) <= 0.25 * onrows.sum()
