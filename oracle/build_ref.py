@@ -192,9 +192,70 @@ def build(force=False):
     exe = os.path.join(OUT, "ref_harness")
     if not newer(exe, *objs):
         run([FC, *OPT, "-o", exe, *objs])
+    build_driver([o for o in objs if o != hobj])
     with open(os.path.join(OUT, "BUILD_INFO.txt"), "w") as f:
         f.write("compiler: %s\nflags: %s\nreference: %s\n" %
                 (run([FC, "--version"]).splitlines()[0], " ".join(OPT), REF))
+    print("build_ref: built", exe)
+    return True
+
+
+# ---- the reference's OWN program: fortran/raytracer_driver.f95 -> oracle/_ref/raytracer -------------------------------
+# It `use`s all seven adapters (raytracer_driver.f95:5-28), so the out-of-scope models (GCPM, IRI, the 3-D Ngo variant,
+# the simple and AT64ThCh models) are compiled too -- only to satisfy the linker; nothing of them is restated anywhere
+# in this repository.  Flags follow the reference's Makefiles (fortran/Makefile:42-48, gcpm/Makefile, iri2007/Makefile:46-55,
+# xform/Makefile) minus gfortran-only options; further departures, each forced by flang:
+#   * raytracer_driver.f95:76 uses the GNU intrinsic iargc(): -cpp -Diargc=command_argument_count;
+#   * AT64ThCh_adapter.f95 passes T04_s / IGRF_GSM as actual arguments without declaring them EXTERNAL: the
+#     declaration is streamed in by sed after its `implicit none` of funcPlasmaParams (never written to disk).
+DRIVER_MODULES = [
+    ("fortran/pp_profile_d.f95", [], None),
+    ("fortran/switch_d.f95", [], None),
+    ("fortran/gcpm_dens_model_adapter.f95", [], None),
+    ("fortran/simple_3d_model_adapter.f95", [], None),
+    ("fortran/ngo_3d_dens_model.f95", [], None),
+    ("fortran/ngo_3d_dens_model_adapter.f95", [], None),
+    ("fortran/AT64ThCh_adapter.f95", [], r"75a\    external :: T04_s, IGRF_GSM"),
+]
+GCPM_SOURCES = ["bulge.for", "gcpm_v24.for", "iri_ps_bridge.for", "iri_ps_eq_bridge.for", "iri_sm.for", "ne_inner_ps_trough.for",
+                "ne_iri_cap.for", "ne_iri_ps_trough.for", "ne_iri_ps_trough_eq.for", "pp_profile.for", "switchon.for"]
+IRI_SOURCES = ["irisub.for", "irifun.for", "iritec.for", "iridreg.for", "igrf.for", "igrf12.for", "cira.for"]
+
+
+def build_driver(path_objs):
+    """Link the reference's driver against the objects ref_harness already uses plus the out-of-scope adapters."""
+    objs = list(path_objs)
+    for rel, flags, sed in DRIVER_MODULES:
+        src = os.path.join(REF, rel)
+        if not os.path.exists(src):
+            print("build_ref: %s missing -- reference driver not built" % rel)
+            return False
+        obj = os.path.join(OBJ, "drv_" + os.path.basename(rel).rsplit(".", 1)[0] + ".o")
+        compile_one(src, obj, flags, sed)
+        objs.append(obj)
+    jobs = []
+    for f in GCPM_SOURCES:
+        obj = os.path.join(OBJ, "gcpm_" + f[:-4] + ".o")
+        jobs.append((os.path.join(REF, "gcpm", f), obj, ["-ffixed-form", "-ffixed-line-length-132"], None))
+        objs.append(obj)
+    for f in IRI_SOURCES:
+        obj = os.path.join(OBJ, "iri_" + f[:-4] + ".o")
+        jobs.append((os.path.join(REF, "iri2007", f), obj, ["-fno-automatic", "-ffixed-form", "-ffixed-line-length-132"], None))
+        objs.append(obj)
+    xdir = os.path.join(REF, "xform")
+    for f in sorted(os.listdir(xdir)):
+        if f.lower().endswith(".for"):
+            obj = os.path.join(OBJ, "xs_" + f[:-4] + ".o")
+            jobs.append((os.path.join(xdir, f), obj, ["-ffixed-form"], None))
+            objs.append(obj)
+    with ThreadPoolExecutor(8) as ex:
+        list(ex.map(lambda j: compile_one(*j), jobs))
+    dsrc = os.path.join(REF, "fortran", "raytracer_driver.f95")
+    dobj = os.path.join(OBJ, "drv_raytracer_driver.o")
+    compile_one(dsrc, dobj, ["-cpp", "-Diargc=command_argument_count"], None)
+    exe = os.path.join(OUT, "raytracer")
+    if not newer(exe, dobj, *objs):
+        run([FC, *OPT, "-o", exe, dobj, *objs])
     print("build_ref: built", exe)
     return True
 

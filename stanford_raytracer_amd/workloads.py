@@ -201,3 +201,13 @@ def make_points_config5(seed, n_uniform=200_000, n_importance=600_000, n_shell=2
     ps = v * (R_E + rng.uniform(0.0, 2000e3, (n_shell, 1)))
     pts = np.concatenate([pu, pi, ps], axis=0)
     return pts, analytic_lnN(pts)
+
+
+def synthetic_derivs(shape):
+    """Seven file-supplied derivative blocks (computederivatives = 1, interp_dens_model_adapter.f95:107-116) for a grid of
+    `shape` = (nz, ny, nx, nspec): exactly reproducible numbers (small integers / 8 times a power of ten, no libm), of the
+    size ln N's derivatives have per metre.  Order: dfdx dfdy dfdz d2fdxdy d2fdxdz d2fdydz d3fdxdydz."""
+    nz, ny, nx, ns = shape
+    k, j, i, s = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), np.arange(ns), indexing="ij")
+    scale = [1e-7, 1e-7, 1e-7, 1e-14, 1e-14, 1e-14, 1e-21]
+    return [scale[a] * (((i * 7 + j * 13 + k * 29 + s * 5 + a * 3) % 17) - 8).astype(np.float64) / 8.0 for a in range(7)]

@@ -89,3 +89,17 @@ def vrel(a, b):
     """|a-b| / |b| over the last axis (vector-relative error)."""
     a, b = np.asarray(a), np.asarray(b)
     return np.linalg.norm(a - b, axis=-1) / np.maximum(np.linalg.norm(b, axis=-1), 1e-300)
+
+
+def parse_ray_file(path):
+    """A .ray file in the driver's record format (raytracer_driver.f95:1197-1217, nspec = 4, 822 characters):
+    -> array [records, 36] = raynum, stopcond, t, pos3, vprel3, vgrel3, n3, B03, w, nspec, qs4, ms4, Ns4, nus4."""
+    rows = []
+    for line in open(path):
+        assert len(line.rstrip("\n")) == 10 + 10 + 17 * 24 + 10 + 16 * 24
+        head = [int(line[0:10]), int(line[10:20])]
+        vals = [float(line[20 + 24 * i:44 + 24 * i]) for i in range(17)]
+        nspec = int(line[428:438])
+        tail = [float(line[438 + 24 * i:462 + 24 * i]) for i in range(16)]
+        rows.append(head + vals + [nspec] + tail)
+    return np.array(rows)

@@ -6,23 +6,11 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import GOLDEN_DIR, ROOT, vrel
+from conftest import GOLDEN_DIR, ROOT, parse_ray_file, vrel
 from stanford_raytracer_amd import workloads as wl
 
 pytestmark = pytest.mark.gpu
 BIN = os.path.join(ROOT, "stanford_raytracer_amd", "bin")
-
-
-def parse_ray_file(path):
-    rows = []
-    for line in open(path):
-        assert len(line.rstrip("\n")) == 10 + 10 + 17 * 24 + 10 + 16 * 24
-        head = [int(line[0:10]), int(line[10:20])]
-        vals = [float(line[20 + 24 * i:44 + 24 * i]) for i in range(17)]
-        nspec = int(line[428:438])
-        tail = [float(line[438 + 24 * i:462 + 24 * i]) for i in range(16)]
-        rows.append(head + vals + [nspec] + tail)
-    return np.array(rows)
 
 
 def test_cli_config1_matches_reference_ray_file(tmp_path, cfgfiles, golden):
@@ -57,6 +45,75 @@ def test_cli_config1_matches_reference_ray_file(tmp_path, cfgfiles, golden):
         out2 = tmp_path / "out_fortran.ray"
         subprocess.run([fdrv, cfgfiles["ngo"], str(rf), str(out2)], check=True)
         assert out2.read_text() == out.read_text()
+
+
+def test_cli_adaptive_model3_matches_the_reference_drivers_file(tmp_path, grid16):
+    """An adaptive modelnum-3 run against the .ray file the reference's OWN program wrote (oracle/_ref/raytracer =
+    fortran/raytracer_driver.f95 compiled where it lies; tests/golden/make_driver_golden.py): same flags, same input
+    files.  Every integer / format column and every row 0 must be equal; the adaptive rows are compared per ray over
+    the records both files hold (step sequences may split after a few steps: SURVEY A-9)."""
+    F, b, qs, ms = grid16
+    gf = tmp_path / "grid16.txt"
+    wl.write_grid_file(str(gf), F, b, qs, ms)
+    p0, d0, w0 = wl.appendix_b_rays()
+    rf = tmp_path / "rays.txt"
+    wl.write_rays_file(str(rf), p0, d0, w0)
+    out = tmp_path / "out.ray"
+    cmd = [os.path.join(BIN, "raytracer"), "--outputper=16", "--tmax=0.2", "--fixedstep=0", "--modelnum=3",
+           "--interp_interpfile=%s" % gf, "--dt0=0.001", "--dtmax=0.1", "--root=2", "--maxerr=5e-4", "--maxsteps=2000",
+           "--minalt=%r" % wl.MINALT, "--inputraysfile=%s" % rf, "--outputfile=%s" % out, "--yearday=2010001",
+           "--milliseconds_day=0", "--use_tsyganenko=0", "--use_igrf=0"]
+    subprocess.run(cmd, check=True)
+    mine = parse_ray_file(str(out))
+    ref = parse_ray_file(os.path.join(GOLDEN_DIR, "driver_interp_adaptive.ray"))
+    assert set(mine[:, 0]) == set(ref[:, 0]) == set(range(1, 17))
+    stop_agree, rows_mine, rows_ref = 0, 0, 0
+    for ray in range(1, 17):
+        a, r = mine[mine[:, 0] == ray], ref[ref[:, 0] == ray]
+        rows_mine += len(a)
+        rows_ref += len(r)
+        stop_agree += int(a[0, 1] == r[0, 1])
+        # row 0: the launch point, k0 on the whistler root, plasma and field there
+        assert a[0, 2] == r[0, 2] == 0.0 and np.array_equal(a[0, 3:6], r[0, 3:6])
+        assert vrel(a[0, 12:15], r[0, 12:15]) <= 1e-9                      # n
+        assert vrel(a[0, 15:18], r[0, 15:18]) <= 2e-7                      # B0 (float32 round trip)
+        assert np.max(np.abs(a[0, 28:32] - r[0, 28:32]) / r[0, 28:32]) <= 1e-11   # Ns
+        assert vrel(a[0, 6:9], r[0, 6:9]) <= 1e-6 and vrel(a[0, 9:12], r[0, 9:12]) <= 1e-6   # vprel, vgrel (finite differences)
+        # constants of the record
+        assert np.array_equal(a[:, 18], np.full(len(a), r[0, 18])) and np.all(a[:, 19] == 4)
+        assert np.array_equal(a[:, 20:28], np.tile(r[0, 20:28], (len(a), 1))) and np.all(a[:, 32:36] == 0.0)
+        assert np.all(a[:, 1] == a[0, 1])                                   # the final stop code on every row
+        # first kept row after the launch (16 accepted steps): same time stamp unless the step sequences already split
+        # (bar: SURVEY A-9's curve tolerance; the oracle-yardstick trajectory bars are in tests/test_gpu_trajectory_stats.py)
+        if len(a) > 1 and len(r) > 1 and a[1, 2] == r[1, 2]:
+            assert vrel(a[1, 3:6], r[1, 3:6]) <= 1e-3
+    assert stop_agree >= 14
+    assert abs(rows_mine - rows_ref) <= 0.1 * rows_ref
+
+
+def test_cli_devices_flag_shards_and_keeps_ray_order(tmp_path, cfgfiles):
+    """--devices=0,0 (two host threads, two model replicas, contiguous shards -- both on the one card of the GPU box): the
+    .ray file is byte-identical to the single-device run; so is a run with more devices than rays."""
+    pos, d, w = wl.launch_set(37, 41)
+    rf = tmp_path / "rays.txt"
+    wl.write_rays_file(str(rf), pos, d, w)
+    base = [os.path.join(BIN, "raytracer"), "--outputper=3", "--dt0=0.001", "--dtmax=0.1", "--tmax=0.05", "--root=2",
+            "--fixedstep=0", "--maxerr=5e-4", "--maxsteps=80", "--minalt=%r" % wl.MINALT, "--inputraysfile=%s" % rf,
+            "--modelnum=1", "--ngo_configfile=%s" % cfgfiles["ngo"], "--yearday=2010001", "--milliseconds_day=0"]
+    outs = {}
+    for tag, extra in (("one", []), ("two", ["--devices=0,0"]), ("three", ["--devices=0,0,0", "--chunk_rays=64"])):
+        o = tmp_path / (tag + ".ray")
+        subprocess.run(base + ["--outputfile=%s" % o] + extra, check=True)
+        outs[tag] = o.read_bytes()
+        assert not list(tmp_path.glob(tag + ".ray.part*"))
+    assert len(outs["one"]) > 0 and outs["one"] == outs["two"] == outs["three"]
+    one = tmp_path / "single.txt"
+    wl.write_rays_file(str(one), pos[:1], d[:1], w[:1])
+    o1, o2 = tmp_path / "s1.ray", tmp_path / "s2.ray"
+    args = [a for a in base if not a.startswith("--inputraysfile")] + ["--inputraysfile=%s" % one]
+    subprocess.run(args + ["--outputfile=%s" % o1], check=True)
+    subprocess.run(args + ["--outputfile=%s" % o2, "--devices=0,0"], check=True)   # second shard is empty
+    assert o1.read_bytes() == o2.read_bytes()
 
 
 def test_cli_rejects_out_of_scope_requests(tmp_path, cfgfiles):

@@ -273,3 +273,37 @@ def test_interp_other_shapes_match_the_oracle(nspec, dims):
     pairs = sorted(set(zip(stop[stop != ostop].tolist(), ostop[stop != ostop].tolist())))
     assert np.mean(stop == ostop) >= 0.9, "fates differ: %s  n=%d/%d" % (pairs, (stop != ostop).sum(), len(stop))
     assert abs(int(nrows.sum()) - int(onrows.sum())) <= 0.1 * onrows.sum()
+
+
+def test_interp_file_supplied_derivatives(grid16, golden, tmp_path):
+    """A modelnum-3 grid with computederivatives = 1: the seven derivative blocks come from the file / the caller
+    (interp_dens_model_adapter.f95:107-116) instead of the library's own finite differences.  funcPlasmaParams and the
+    gradients against the reference's own outputs for the same file (tests/golden/make_interp_derivs_golden.py), through
+    both entry points (host arrays, text file), and against the oracle."""
+    import os
+
+    from conftest import GOLDEN_DIR
+    from oracle import oracle
+    from stanford_raytracer_amd import api, workloads as wl
+
+    F, b, qs, ms = grid16
+    derivs = wl.synthetic_derivs(F.shape)
+    gd = np.load(os.path.join(GOLDEN_DIR, "interp_derivs_golden.npz"))
+    gf = str(tmp_path / "grid16_derivs.txt")
+    wl.write_grid_file(gf, F, b, qs, ms, derivs=derivs)
+    x, ref = golden["g0_interp_x"], gd["g0_out"]
+    models = [api.Model.interp(F, b, qs, ms, derivs=derivs), api.Model.interp_file(gf)]
+    outs = [m.plasma_params(x) for m in models]
+    assert np.array_equal(outs[0], outs[1])
+    g = outs[0]
+    assert rel(g[:, 4:8], ref[:, 4:8]).max() <= 1e-11
+    assert vrel(g[:, 16:19], ref[:, 16:19]).max() <= 2e-7
+    assert rel(g[:, 4:8], golden["g0_interp_out"][:, 4:8]).max() > 1e-2     # not the finite-difference grid's numbers
+    gin, gref = gd["g2_in"], gd["g2_out"]
+    gg = models[0].gradients(gin[:, 0:3], gin[:, 3:6], gin[:, 6], 1e-6)
+    assert vrel(gg[:, 0:3], gref[:, 0:3]).max() <= 1e-7
+    ex = vrel(gg[:, 4:7], gref[:, 4:7])
+    assert np.median(ex) <= 1e-7 and np.percentile(ex, 95) <= 1e-4          # the bars of the finite-difference grid (G2)
+    o = oracle.Model.interp_file(gf)
+    op = np.array([np.concatenate(o.plasma_params(p)) for p in x])
+    assert rel(g[:, 4:8], op[:, 4:8]).max() <= 1e-11

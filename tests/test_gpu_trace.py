@@ -91,21 +91,35 @@ def curve_distance(rows_a, n_a, rows_b, n_b, tmax):
 @pytest.mark.parametrize("name,tag", [("ngo", "g4_ngo_adaptive"), ("ngoducts", "g4_ngoducts_adaptive"),
                                       ("interp", "g4_interp_adaptive"), ("ngo", "g4_ngo_launch"),
                                       ("interp", "g4_interp_launch")])
-def test_adaptive_trajectories(golden, gpu_models, name, tag):
+def test_adaptive_trajectories(golden, gpu_models, oracle_models, name, tag):
+    """The reference's own adaptive rows (goldens) for the 16 Appendix-B rays and the launch-set rays.  Bars: the oracle
+    (bit-identical to the reference on these runs) against itself under a 1e-9 shift of the launch points, as in
+    test_fixed_step_trajectories; the statistics on 1 000+ rays are in tests/test_gpu_trajectory_stats.py."""
     rays = golden["g4_launch_rays" if tag.endswith("launch") else "g4_rays"]
     prm = golden[tag + "_params"]
     ref_rows, ref_n, ref_stop = golden[tag + "_rows"], golden[tag + "_nrows"], golden[tag + "_stop"]
-    rows, nrows, stop, _ = gpu_models[name].trace(rays[:, :3], rays[:, 3:6], rays[:, 6], outputper=1, dt0=prm[0],
-                                                  dtmax=prm[1], tmax=prm[2], maxerr=prm[3], minalt=prm[4],
-                                                  maxsteps=int(prm[5]), root=int(prm[6]), fixedstep=0, del_=DELS[name])
-    assert np.mean(stop == ref_stop) >= 0.9
+    kw = dict(dt0=prm[0], dtmax=prm[1], tmax=prm[2], maxerr=prm[3], minalt=prm[4], maxsteps=int(prm[5]), root=int(prm[6]),
+              fixedstep=0, del_=DELS[name])
+    rows, nrows, stop, _ = gpu_models[name].trace(rays[:, :3], rays[:, 3:6], rays[:, 6], outputper=1, **kw)
+    om = oracle_models[name]
+    cap = int(ref_rows.shape[1])
+    base = om.trace(rays[:, :3], rays[:, 3:6], rays[:, 6], capacity=cap, **kw)
+    assert np.array_equal(base[1], ref_n) and np.array_equal(base[2], ref_stop)     # the oracle IS the reference here
+    yard_curve, yard_stop, yard_rows = 0.0, 1.0, 0
+    for eps in (1e-9, -1e-9):
+        pert = om.trace(rays[:, :3] * (1 + eps), rays[:, 3:6], rays[:, 6], capacity=cap, **kw)
+        yard_curve = max(yard_curve, curve_distance(pert[0], pert[1], base[0], base[1], 0.1))
+        yard_stop = min(yard_stop, float(np.mean(pert[2] == base[2])))
+        yard_rows = max(yard_rows, abs(int(pert[1].sum()) - int(base[1].sum())))
+    assert np.mean(stop == ref_stop) >= min(0.9, yard_stop - 1.0 / len(stop))
     # first attempt: always accepted at dt0 and never grown (SURVEY A-1, flang semantics); the second
     # step therefore ends at 2 dt0 at the latest
     both = (nrows > 2) & (ref_n > 2)
     assert np.allclose(rows[both, 1, 0], prm[0]) and np.all(rows[both, 2, 0] <= 2 * prm[0] * (1 + 1e-12))
-    assert abs(int(nrows.sum()) - int(ref_n.sum())) <= 0.15 * ref_n.sum()
-    # curves: position on a common time grid over the early part of the run
-    assert curve_distance(rows, nrows, ref_rows, ref_n, 0.1) <= (1e-3 if name != "interp" else 2e-2)
+    assert abs(int(nrows.sum()) - int(ref_n.sum())) <= max(3 * yard_rows, 0.05 * ref_n.sum())
+    # curves: position on a common time grid over the early part of the run; no worse than 3x the oracle against itself
+    # (floor: SURVEY A-9's 1e-3)
+    assert curve_distance(rows, nrows, ref_rows, ref_n, 0.1) <= max(3 * yard_curve, 1e-3)
 
 
 def test_field_aligned_launch(golden, gpu_models):

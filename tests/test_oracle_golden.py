@@ -219,3 +219,21 @@ def test_sampler_oracle_follows_the_reference_rules(oracle_models):
     # a looser starting tolerance needs more passes but ends beyond adaptive_nmax all the same
     s3, c3 = o.build_samples(b, **dict(kw, initial_tol=64.0))
     assert c3[3] >= 800
+
+
+# ---- modelnum 3 with derivative blocks in the file (computederivatives = 1, interp_dens_model_adapter.f95:107-116) ----
+def test_interp_file_supplied_derivatives(grid16, tmp_path):
+    from oracle import oracle
+    from stanford_raytracer_amd import workloads as wl
+
+    F, b, qs, ms = grid16
+    gd = np.load(os.path.join(GOLDEN_DIR, "interp_derivs_golden.npz"))
+    gf = str(tmp_path / "grid16_derivs.txt")
+    wl.write_grid_file(gf, F, b, qs, ms, derivs=wl.synthetic_derivs(F.shape))
+    m = oracle.Model.interp_file(gf)
+    x = np.load(os.path.join(GOLDEN_DIR, "golden.npz"))["g0_interp_x"]
+    mine = np.array([np.concatenate(m.plasma_params(p)) for p in x])
+    assert close(mine, gd["g0_out"])
+    assert np.mean(mine == gd["g0_out"]) > 0.999
+    g2 = np.array([m.grad(r[0:3], r[3:6], r[6], r[7]) for r in gd["g2_in"]])
+    assert close(g2, gd["g2_out"], rtol=1e-12)

@@ -52,3 +52,51 @@ def test_adaptive_run_fresh(oracle_models, ref_models):
                                    maxsteps=300, minalt=wl.MINALT, del_=1e-4)
     assert [o["rows"].shape[0] for o in out] == nrows.tolist()
     assert [o["stopcond"] for o in out] == stop.tolist()
+
+
+# ---- the reference's OWN program (oracle/_ref/raytracer = fortran/raytracer_driver.f95, built by oracle/build_ref.py) ----
+import os
+import subprocess
+import sys
+
+from conftest import GOLDEN_DIR, ROOT, parse_ray_file
+
+DRIVER = os.path.join(ROOT, "oracle", "_ref", "raytracer")
+needs_driver = pytest.mark.skipif(not os.path.exists(DRIVER), reason="oracle/_ref/raytracer not built")
+
+
+@needs_driver
+def test_reference_driver_reproduces_the_committed_ray_files(tmp_path, cfgfiles, grid16):
+    """The committed .ray goldens ARE what the reference's own flag parsing (raytracer_driver.f95:181-228) and record
+    writer (:1197-1217) produce: rerun it here, byte for byte."""
+    sys.path.insert(0, GOLDEN_DIR)
+    import make_driver_golden as mk
+
+    p0, d0, w0 = wl.appendix_b_rays()
+    rays = str(tmp_path / "rays.txt")
+    wl.write_rays_file(rays, p0, d0, w0)
+    out1 = str(tmp_path / "c1.ray")
+    subprocess.run([DRIVER] + mk.config1_flags(rays, out1, cfgfiles["ngo"]), check=True, stdout=subprocess.DEVNULL)
+    assert open(out1, "rb").read() == open(os.path.join(GOLDEN_DIR, "config1_outputper25.ray"), "rb").read()
+    F, b, qs, ms = grid16
+    gf = str(tmp_path / "grid16.txt")
+    wl.write_grid_file(gf, F, b, qs, ms)
+    out3 = str(tmp_path / "c3.ray")
+    subprocess.run([DRIVER] + mk.interp_flags(rays, out3, gf), check=True, stdout=subprocess.DEVNULL)
+    assert open(out3, "rb").read() == open(os.path.join(GOLDEN_DIR, "driver_interp_adaptive.ray"), "rb").read()
+
+
+def test_oracle_reproduces_the_drivers_adaptive_file(oracle_models):
+    """The C oracle traced with the driver's parameters gives the driver's own adaptive model-3 file: same records,
+    same stop codes, and the numbers to the 16 significant digits the record format holds (no reference build needed:
+    the file is committed)."""
+    ref = parse_ray_file(os.path.join(GOLDEN_DIR, "driver_interp_adaptive.ray"))
+    p0, d0, w0 = wl.appendix_b_rays()
+    rows, nrows, stop, _ = oracle_models["interp"].trace(p0, d0, w0, capacity=2000, fixedstep=0, dt0=1e-3, dtmax=0.1, tmax=0.2,
+                                                         maxerr=5e-4, maxsteps=2000, minalt=wl.MINALT, del_=1e-6)
+    for ray in range(16):
+        r = ref[ref[:, 0] == ray + 1]
+        kept = rows[ray, 0:nrows[ray]:16]
+        assert len(kept) == len(r) and np.all(r[:, 1] == stop[ray])
+        assert np.allclose(kept[:, 0:16], r[:, 2:18], rtol=2e-15, atol=0)     # t, pos, vprel, vgrel, n, B0
+        assert np.allclose(kept[:, 16:20], r[:, 28:32], rtol=2e-15, atol=0)   # Ns
