@@ -130,7 +130,10 @@ int main(int argc, char **argv) {
          "  model 3: --interp_interpfile --yearday --milliseconds_day --use_tsyganenko=0|1 --use_igrf=0|1\n"
          "  model 4: model 3 flags + --scattered_interp_window_scale --scattered_interp_order\n"
          "           --scattered_interp_exact --scattered_interp_local_window_scale\n"
-         "  extra:   --device=N | --devices=0,1,..  --first_attempt_policy=0|1  --chunk_rays=N  --ray_order=0|1\n"
+         "  extra:   --device=N | --devices=0,1,..  --chunk_rays=N  --ray_order=0|1\n"
+         "           --first_attempt_policy=1|0: error estimate of a ray's first adaptive attempt, where the reference reads an\n"
+         "             unset variable: 1 (default) = from the k term alone, as the reference's gfortran build behaves;\n"
+         "             0 = NaN => accepted at dt0, dt not grown, as a flang build behaves (the goldens of this repository)\n"
          "  tools:   --grid2bin_in=<text grid> --grid2bin_out=<binary grid>   (convert and exit; --interp_interpfile\n"
          "           accepts either form);  --pts2bin_in / --pts2bin_out: the same for model-4 sample files\n"
          "           --buildsamples=1 --filename=<out> --minx .. --maxz --n_initial_uniform ... (the reference's random grid\n"
@@ -218,7 +221,14 @@ int main(int argc, char **argv) {
   get_int("outputper", p.outputper);
   if (p.outputper < 1) p.outputper = 1; // the reference's mod(i-1, outputper) with outputper <= 0 is undefined; the library clamps too
   get_int("device", device);
+  // The first adaptive attempt (SURVEY A-1).  Default 1 = the step pattern of the reference's own
+  // toolchain (gfortran: MAX(k_term, NaN) = k_term, Makefile:3,10); 0 = a flang build's (NaN: accept, no growth).
+  p.first_attempt_policy = 1;
   get_int("first_attempt_policy", p.first_attempt_policy);
+  if (p.first_attempt_policy != 0 && p.first_attempt_policy != 1) {
+    fprintf(stderr, "raytracer: --first_attempt_policy must be 0 or 1\n");
+    return 2;
+  }
   get_int("ray_order", p.ray_order);
   get_int("chunk_rays", chunk);
   // ours: --devices=0,1,.. = one host thread and one model replica per GPU, contiguous shards of the ray file

@@ -60,6 +60,7 @@ def test_cli_adaptive_model3_matches_the_reference_drivers_file(tmp_path, grid16
     wl.write_rays_file(str(rf), p0, d0, w0)
     out = tmp_path / "out.ray"
     cmd = [os.path.join(BIN, "raytracer"), "--outputper=16", "--tmax=0.2", "--fixedstep=0", "--modelnum=3",
+           "--first_attempt_policy=0",   # the golden comes from a flang build of the reference
            "--interp_interpfile=%s" % gf, "--dt0=0.001", "--dtmax=0.1", "--root=2", "--maxerr=5e-4", "--maxsteps=2000",
            "--minalt=%r" % wl.MINALT, "--inputraysfile=%s" % rf, "--outputfile=%s" % out, "--yearday=2010001",
            "--milliseconds_day=0", "--use_tsyganenko=0", "--use_igrf=0"]
@@ -173,7 +174,8 @@ def test_cli_models_3_and_4_write_what_the_library_computes(tmp_path, grid16, po
     rf = tmp_path / "rays.txt"
     wl.write_rays_file(str(rf), pos, d, w)
     out = tmp_path / "out.ray"
-    common = ["--outputper=5", "--dt0=0.001", "--dtmax=0.1", "--tmax=0.05", "--root=2", "--fixedstep=0", "--maxerr=5e-4",
+    common = ["--first_attempt_policy=0",   # what api.make_params defaults to (the CLI's default is 1)
+              "--outputper=5", "--dt0=0.001", "--dtmax=0.1", "--tmax=0.05", "--root=2", "--fixedstep=0", "--maxerr=5e-4",
               "--maxsteps=60", "--minalt=%r" % wl.MINALT, "--inputraysfile=%s" % rf, "--outputfile=%s" % out,
               "--yearday=2010001", "--milliseconds_day=0", "--use_tsyganenko=0", "--use_igrf=0", "--chunk_rays=128",
               "--ray_order=1", "--modelnum=%d" % modelnum]
@@ -240,8 +242,8 @@ def test_cli_buildsamples_pts2bin_and_damping(tmp_path, cfgfiles):
     rf, out, dmp = tmp_path / "rays.txt", tmp_path / "o.ray", tmp_path / "o.damp"
     pos0, dir0, w0 = wl.launch_set(6, 3)
     wl.write_rays_file(str(rf), pos0, dir0, w0)
-    run = [exe, "--dt0=1e-3", "--dtmax=0.02", "--tmax=0.1", "--root=2", "--fixedstep=0", "--maxerr=5e-4", "--maxsteps=200",
-           "--minalt=%r" % wl.MINALT, "--outputper=4", "--inputraysfile=%s" % rf, "--outputfile=%s" % out,
+    run = [exe, "--first_attempt_policy=0", "--dt0=1e-3", "--dtmax=0.02", "--tmax=0.1", "--root=2", "--fixedstep=0", "--maxerr=5e-4",
+           "--maxsteps=200", "--minalt=%r" % wl.MINALT, "--outputper=4", "--inputraysfile=%s" % rf, "--outputfile=%s" % out,
            "--damping_out=%s" % dmp] + model
     assert subprocess.run(run).returncode == 0
     p = api.make_params(dt0=1e-3, dtmax=0.02, tmax=0.1, maxerr=5e-4, maxsteps=200, minalt=wl.MINALT, outputper=4, del_=1e-4)
