@@ -301,9 +301,10 @@ def run_workload(ctx, name, steps, warmup, rays_override=0, nstream=1, keep=Fals
                     float(np.mean([t.get("pack_s", 0.0) for t in tms])) if steps else 0.0])
     tot = np.array([int(c[1]), int(c[2]), int(c[3])], dtype=np.int64)
     if dist is not None:
-        t = torch.tensor(red, dtype=torch.float64, device=dev)
+        rdev = dev if dist.get_backend() == "nccl" else torch.device("cpu")  # (gloo rehearsal: host tensors)
+        t = torch.tensor(red, dtype=torch.float64, device=rdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        s = torch.tensor(tot, dtype=torch.int64, device=dev)
+        s = torch.tensor(tot, dtype=torch.int64, device=rdev)
         dist.all_reduce(s, op=dist.ReduceOp.SUM)
         red, tot = t.cpu().numpy(), s.cpu().numpy()
     o = batch.out[0]
