@@ -11,6 +11,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <future>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -317,35 +319,56 @@ int main(int argc, char **argv) {
       }
       fclose(f);
     }
+    // chunk k's records are formatted and written (all host cores, srt_write_ray_file) while chunk k+1 is on the GPU
+    struct Chunk {
+      std::vector<double> rows, rate, mag;
+      std::vector<int32_t> nrows, stop, flag;
+    };
+    std::future<int> pending;
+    auto finish = [&]() -> int {
+      if (!pending.valid()) return 0;
+      const int rc = pending.get();
+      if (rc) fprintf(stderr, "raytracer: writing %s failed\n", sh.out.c_str());
+      return rc;
+    };
     for (int64_t lo = sh.lo; lo < sh.hi; lo += maxchunk) {
       int64_t n = sh.hi - lo < maxchunk ? sh.hi - lo : maxchunk;
-      std::vector<double> rows((size_t)n * slots * SRT_ROW);
-      std::vector<int32_t> nrows(n), stop(n);
+      auto c = std::make_shared<Chunk>();
+      c->rows.resize((size_t)n * slots * SRT_ROW);
+      c->nrows.resize(n);
+      c->stop.resize(n);
       int64_t steps = 0;
-      CHECK(srt_trace_batch(m, &q, n, pos0 + 3 * lo, dir0 + 3 * lo, w0 + lo, rows.data(), nrows.data(), stop.data(), &steps));
+      CHECK(srt_trace_batch(m, &q, n, pos0 + 3 * lo, dir0 + 3 * lo, w0 + lo, c->rows.data(), c->nrows.data(), c->stop.data(), &steps));
       sh.steps += steps;
-      CHECK(srt_write_ray_file(sh.out.c_str(), 1, lo + 1, n, &q, nspec, qs, ms, w0 + lo, rows.data(), nrows.data(), stop.data()));
-      if (!sh.damp.empty()) {
+      const bool damp = !sh.damp.empty();
+      if (damp) {
         // the MATLAB post-processor (matlab/damping/test_dampray.m) on the rows just traced: one record per kept row
-        std::vector<double> rate((size_t)n * slots), mag((size_t)n * slots);
-        std::vector<int32_t> flag((size_t)n * slots);
-        CHECK(srt_damping(&dpar, nspec, qs, ms, slots, q.outputper, n, rows.data(), nrows.data(), w0 + lo, rate.data(), mag.data(), flag.data()));
-        FILE *f = fopen(sh.damp.c_str(), lo == sh.lo ? "w" : "a");
-        if (!f) {
-          fprintf(stderr, "raytracer: cannot open %s\n", sh.damp.c_str());
-          return 1;
-        }
-        for (int64_t i = 0; i < n; ++i) {
-          const int kept = nrows[i] > 0 ? (nrows[i] - 1) / q.outputper + 1 : 0;
-          for (int r = 0; r < kept && r < slots; ++r) {
-            const size_t idx = (size_t)i * slots + r;
-            fprintf(f, "%10lld%10d%25.15E%25.15E%25.15E%10d\n", (long long)(lo + i + 1), r * q.outputper + 1, rows[idx * SRT_ROW], rate[idx], mag[idx],
-                    (int)flag[idx]);
-          }
-        }
-        fclose(f);
+        c->rate.resize((size_t)n * slots);
+        c->mag.resize((size_t)n * slots);
+        c->flag.resize((size_t)n * slots);
+        CHECK(srt_damping(&dpar, nspec, qs, ms, slots, q.outputper, n, c->rows.data(), c->nrows.data(), w0 + lo, c->rate.data(), c->mag.data(), c->flag.data()));
       }
+      if (int rc = finish()) return rc;
+      const bool first = lo == sh.lo;
+      pending = std::async(std::launch::async, [=, &sh, &q]() -> int {
+        if (srt_write_ray_file(sh.out.c_str(), 1, lo + 1, n, &q, nspec, qs, ms, w0 + lo, c->rows.data(), c->nrows.data(), c->stop.data())) return 1;
+        if (damp) {
+          FILE *f = fopen(sh.damp.c_str(), first ? "w" : "a");
+          if (!f) return 1;
+          for (int64_t i = 0; i < n; ++i) {
+            const int kept = c->nrows[i] > 0 ? (c->nrows[i] - 1) / q.outputper + 1 : 0;
+            for (int r = 0; r < kept && r < slots; ++r) {
+              const size_t idx = (size_t)i * slots + r;
+              fprintf(f, "%10lld%10d%25.15E%25.15E%25.15E%10d\n", (long long)(lo + i + 1), r * q.outputper + 1, c->rows[idx * SRT_ROW], c->rate[idx],
+                      c->mag[idx], (int)c->flag[idx]);
+            }
+          }
+          if (fclose(f) != 0) return 1;
+        }
+        return 0;
+      });
     }
+    if (int rc = finish()) return rc;
     srt_model_destroy(m);
     return 0;
   };

@@ -24,6 +24,57 @@ def test_ray_file_writer_matches_reference_bytes(golden, tmp_path):
     assert out.read_text() == ref
 
 
+def test_ray_file_writer_adaptive_golden_threads_and_append(oracle_models, tmp_path, monkeypatch):
+    """The writer formats disjoint ray ranges on all host cores and pwrites the fixed-length records in place.  Fed the
+    oracle's rows (bit-identical to the reference's on this run), it must give the reference DRIVER's own adaptive model-3
+    file byte for byte -- for any thread count, and when the file is built by appending chunks as the CLI does."""
+    ref = open(os.path.join(GOLDEN_DIR, "driver_interp_adaptive.ray"), "rb").read()
+    p0, d0, w0 = wl.appendix_b_rays()
+    rows_all, nrows, stop, _ = oracle_models["interp"].trace(p0, d0, w0, capacity=2000, fixedstep=0, dt0=1e-3, dtmax=0.1, tmax=0.2,
+                                                             maxerr=5e-4, maxsteps=2000, minalt=wl.MINALT, del_=1e-6)
+    p = api.make_params(maxsteps=2000, outputper=16)
+    rows = np.ascontiguousarray(rows_all[:, ::16])
+    assert rows.shape[1] == api.lib().srt_rows_per_ray(__import__("ctypes").byref(p))
+    for nth in ("1", "3", "16", "64"):      # more threads than rays included
+        monkeypatch.setenv("SRT_IO_THREADS", nth)
+        out = tmp_path / ("t%s.ray" % nth)
+        api.write_ray_file(str(out), (4, wl.QS, wl.MS), p, w0, rows, nrows, stop)
+        assert out.read_bytes() == ref, nth
+    monkeypatch.setenv("SRT_IO_THREADS", "4")
+    out = tmp_path / "chunks.ray"
+    for lo, hi in ((0, 5), (5, 6), (6, 16)):
+        api.write_ray_file(str(out), (4, wl.QS, wl.MS), p, w0[lo:hi], rows[lo:hi], nrows[lo:hi], stop[lo:hi], raynum0=lo + 1,
+                           append=lo > 0)
+    assert out.read_bytes() == ref
+    # no rays: an empty file, as the reference's open(status="replace") leaves it
+    api.write_ray_file(str(out), (4, wl.QS, wl.MS), p, w0[:0], rows[:0], nrows[:0], stop[:0])
+    assert out.read_bytes() == b""
+
+
+def test_es24_matches_printf_on_many_values(tmp_path):
+    """es24.15e3 = 16 significant digits, correctly rounded, three exponent digits: against Python's own %.15E on
+    320 k values over the whole double range (incl. subnormals, halfway cases, the largest double)."""
+    rng = np.random.default_rng(0)
+    vals = np.concatenate([rng.normal(size=20000 * 16) * 10.0 ** rng.integers(-308, 308, size=20000 * 16),
+                           [0.0, -0.0, 5e-324, 1.7976931348623157e308, 0.1, 0.5, 1.0000000000000005, 9.9999999999999995e22, 1e23,
+                            2.5e-5, 1.5, 2.5, 3.5e15, 2.2250738585072014e-308, -4.9e-324, 1e-310]])
+    R = np.zeros((len(vals) // 16, 1, 20))
+    R[:, 0, :16] = vals.reshape(-1, 16)
+    p = api.make_params(maxsteps=1, outputper=1)
+    out = tmp_path / "v.ray"
+    n = len(R)
+    api.write_ray_file(str(out), (4, wl.QS, wl.MS), p, np.ones(n), R, np.ones(n, dtype=np.int32), np.zeros(n, dtype=np.int32))
+
+    def es24(v):
+        m, e = ("%.15E" % v).split("E")
+        return ("%sE%s%03d" % (m, e[0], abs(int(e)))).rjust(24)
+
+    for i, ln in enumerate(open(out)):
+        assert len(ln) == 823
+        got = [ln[20 + 24 * c:44 + 24 * c] for c in range(16)]
+        assert got == [es24(v) for v in R[i, 0, :16]], i
+
+
 def test_es24_special_values(tmp_path):
     p = api.make_params(maxsteps=1, outputper=1)
     rows = np.zeros((1, 1, 20))
