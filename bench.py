@@ -97,7 +97,10 @@ def parse_args(argv=None):
 def kernel_source_hash():
     """sha256 over the sources the kernels are compiled from: a traffic profile belongs to exactly one such hash."""
     h = hashlib.sha256()
-    files = sorted(glob.glob(os.path.join(ROOT, "stanford_raytracer_amd", "csrc", "*"))) + [os.path.join(ROOT, "include", "srt.h")]
+    # what is compiled into device code: the kernel headers and the launch file (not the host-only file formats / CLI)
+    csrc = os.path.join(ROOT, "stanford_raytracer_amd", "csrc")
+    files = sorted(glob.glob(os.path.join(csrc, "*.hpp")) + glob.glob(os.path.join(csrc, "*.h")) + glob.glob(os.path.join(csrc, "*.hip")))
+    files += [os.path.join(ROOT, "include", "srt.h")]
     for f in files:
         if os.path.isfile(f):
             h.update(os.path.basename(f).encode())
