@@ -1266,6 +1266,18 @@ extern "C" int srt_trace_batch_device(srt_model *m, const srt_params *p, int64_t
 #undef SRT_LAUNCH_TRACE1
   HIP_OK(hipGetLastError());
   HIP_OK(hipEventRecord(sl.ev1, st));
+#ifdef SRT_TRIP_TIMING
+  if (getenv("SRT_TRIP_TIMING")) {
+    unsigned long long h[16];
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipMemcpyFromSymbol(h, HIP_SYMBOL(srt_trip_cycles), sizeof h));
+    fprintf(stderr, "srt trip cycles:");
+    for (int i = 0; i < 16; ++i) fprintf(stderr, " %llu", h[i]);
+    fprintf(stderr, "\n");
+    memset(h, 0, sizeof h);
+    HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(srt_trip_cycles), h, sizeof h));
+  }
+#endif
 #ifdef SRT_PHASE_TIMING
   if (m->kind == 4 && getenv("SRT_PHASE_TIMING")) {
     unsigned long long h[16];

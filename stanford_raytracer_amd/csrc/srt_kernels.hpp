@@ -10,6 +10,29 @@
 
 namespace srt {
 
+// Build with -DSRT_TRIP_TIMING for a cycle breakdown of one attempt trip in block 0 (srt_trip_cycles[], printed after a trace
+// launch when the environment variable SRT_TRIP_TIMING is set): 0 stencil densities inside the stages, 1 rest of evalrhs,
+// 2 end-point stencil densities, 3 error term, 4 root re-projection, 5 end-point right-hand side, 6 bookkeeping, 7 trips,
+// 8 trips with <= 8 active lanes, 9 loop top (stop tests, refill), 10 stage bookkeeping.
+#ifdef SRT_TRIP_TIMING
+__device__ unsigned long long srt_trip_cycles[16];
+#define SRT_TT_BEGIN() unsigned long long tt0_ = __builtin_readcyclecounter()
+#define SRT_TT(slot)                                                                                   \
+  do {                                                                                                 \
+    unsigned long long tt1_ = __builtin_readcyclecounter();                                            \
+    if (threadIdx.x == 0) atomicAdd(&srt_trip_cycles[slot], tt1_ - tt0_);           \
+    tt0_ = tt1_;                                                                                       \
+  } while (0)
+#define SRT_TT_COUNT(slot, v)                                                                          \
+  do {                                                                                                 \
+    if (threadIdx.x == 0) atomicAdd(&srt_trip_cycles[slot], (unsigned long long)(v)); \
+  } while (0)
+#else
+#define SRT_TT_BEGIN() do {} while (0)
+#define SRT_TT(slot) do {} while (0)
+#define SRT_TT_COUNT(slot, v) do {} while (0)
+#endif
+
 struct TraceParams {
   double dt0, dtmax, tmax, maxerr, minalt, del;
   int maxsteps, root, fixedstep, outputper, first_attempt_policy, refill_threshold;
@@ -116,9 +139,12 @@ template <class M, class CM>
 __device__ __forceinline__ void evalrhs(const M &m, const CM &cm, const double x[6], double w, double del,
                                         double rhs[6], double *lds, bool need = true) {
   double p[7][3], d[3], Ns[7][4], dk[3], dw, B[3];
+  SRT_TT_BEGIN();
   stencil_points<7>(x, del, p, d);
   m.template density_stencil<0>(x, d, nullptr, Ns, lds, need);
+  SRT_TT(0);
   rhs_from_plasma<7>(cm, x, x + 3, w, d, p, Ns, rhs, dk, dw, B);
+  SRT_TT(1);
 }
 
 // Explicit RK stage loop shared by rk4 (raytracer.f95:504-532) and rk45 (:534-596).
@@ -251,6 +277,7 @@ __global__ __launch_bounds__(64) void trace_kernel(const M *__restrict__ mp, con
   bool first_attempt = true;
   unsigned long long acc_steps = 0, acc_attempts = 0, wave_trips = 0;
   const int threshold = P.refill_threshold > 0 ? P.refill_threshold : 1;
+  SRT_TT_BEGIN();
 
   for (;;) {
     // ---- A. loop-top tests of raytracer_run (:749-763)
@@ -305,10 +332,17 @@ __global__ __launch_bounds__(64) void trace_kernel(const M *__restrict__ mp, con
     // ---- E. one attempt for every lane (:770-817).  Stage 1 = r1 (carried); stages 2.. are evaluated here.
     acc_attempts += active ? 1ull : 0ull;
     ++wave_trips;
+    SRT_TT(9);
+    SRT_TT_COUNT(7, 1);
+#ifdef SRT_TRIP_TIMING
+    const int tt_live_ = __popcll(__ballot(active || needinit)); // (a ballot inside the macro's lane-0 branch would see lane 0 only)
+    SRT_TT_COUNT(8, tt_live_ <= 8 ? 1 : 0);
+#endif
     double est1[6], est2[6];
     {
       double ks[6][6];
       rk_stages(m, cm, tab, x, w, P.del, dt, ks, lds, r1, active);
+      SRT_TT(10); // all stages (slots 0 and 1 are inside it)
       if (FIXED) {
         rk4_combine(x, ks, est2);
 #pragma unroll
@@ -335,6 +369,7 @@ __global__ __launch_bounds__(64) void trace_kernel(const M *__restrict__ mp, con
       pp[NPOST - 1][2] = est1[2];
     }
     m.template density_stencil<NPOST - 7>(est2, dpost, FIXED ? nullptr : est1, NP_, lds, active || needinit);
+    SRT_TT(2);
     PointState ps2;
 #pragma unroll
     for (int s = 0; s < 4; ++s) ps2.Ns[s] = NP_[0][s];
@@ -400,6 +435,7 @@ __global__ __launch_bounds__(64) void trace_kernel(const M *__restrict__ mp, con
         dt = dt * 1.25;
       }
     }
+    SRT_TT(3);
     // ---- F. re-project |k| on the chosen root, keep direction (:819-836)
     double kdir[3] = {est2[3], est2[4], est2[5]};
     if (needinit) { // launch direction (:661-674)
@@ -433,7 +469,9 @@ __global__ __launch_bounds__(64) void trace_kernel(const M *__restrict__ mp, con
     }
     // first-stage right-hand side at the would-be new state (also yields its group-velocity terms)
     double rn[6], dk[3], dw, Bn[3];
+    SRT_TT(4);
     rhs_from_plasma<NPOST>(cm, est2, knew, w, dpost, pp, NP_, rn, dk, dw, Bn, IGRF ? Bpost : nullptr);
+    SRT_TT(5);
     if (needinit) {
       // launch state and row 0 (:693-742)
 #pragma unroll
@@ -514,6 +552,7 @@ __global__ __launch_bounds__(64) void trace_kernel(const M *__restrict__ mp, con
         }
       }
     }
+    SRT_TT(6);
   }
   // per-wave totals
   for (int off = 32; off > 0; off >>= 1) {
