@@ -121,6 +121,10 @@ def pmc_pass(counters, child_args, timeout=420):
     env = dict(os.environ, TMPDIR="/tmp")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
+    # if this process itself runs under a profiler, the child pass must not inherit its tool libraries
+    for k in list(env):
+        if k in ("LD_PRELOAD", "HSA_TOOLS_LIB", "HSA_TOOLS_REPORT_LOAD_FAILURE") or k.startswith(("ROCP_", "ROCPROF", "ROCTRACER_", "ROCPROFILER_")):
+            env.pop(k)
     try:
         r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout)
     except subprocess.TimeoutExpired:
