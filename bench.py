@@ -123,8 +123,14 @@ def pmc_pass(counters, child_args, timeout=420):
         env.pop(k, None)
     # if this process itself runs under a profiler, the child pass must not inherit its tool libraries
     for k in list(env):
-        if k in ("LD_PRELOAD", "HSA_TOOLS_LIB", "HSA_TOOLS_REPORT_LOAD_FAILURE") or k.startswith(("ROCP_", "ROCPROF", "ROCTRACER_", "ROCPROFILER_")):
+        if k in ("HSA_TOOLS_LIB", "HSA_TOOLS_REPORT_LOAD_FAILURE") or k.startswith(("ROCP_", "ROCPROF", "ROCTRACER_", "ROCPROFILER_")):
             env.pop(k)
+    if "LD_PRELOAD" in env:  # only the profiler's own entries; anything else preloaded on this machine stays
+        keep = [x for x in env["LD_PRELOAD"].replace(":", " ").split() if "rocprof" not in x.lower() and "roctracer" not in x.lower()]
+        if keep:
+            env["LD_PRELOAD"] = ":".join(keep)
+        else:
+            env.pop("LD_PRELOAD")
     try:
         r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout)
     except subprocess.TimeoutExpired:
