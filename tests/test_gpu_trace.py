@@ -258,13 +258,22 @@ def test_full_size_config2_ngo_100k(cfgfiles):
     assert np.array_equal(r2, rows[idx]) and np.array_equal(n2, nrows[idx]) and np.array_equal(s2, stop[idx])
 
 
-def test_full_size_config3_interp256_1m():
-    """BASELINE config[2]: 1M rays on the 256^3 grid (34.8 GB coefficient table) -- properties only."""
+@pytest.fixture(scope="module")
+def interp256_model():
     from stanford_raytracer_amd import api
 
     F, b = wl.make_grid(256, half_width=10.0 * wl.R_E)
     m = api.Model.interp(F, b, wl.QS, wl.MS)
     del F
+    yield m
+    m.close()
+
+
+def test_full_size_config3_interp256_1m(interp256_model):
+    """BASELINE config[2]: 1M rays on the 256^3 grid (34.8 GB coefficient table) -- properties only."""
+    from stanford_raytracer_amd import api
+
+    m = interp256_model
     assert m.device_bytes == 257 ** 3 * 4 * 64 * 8
     pos, d, w = wl.launch_set(1_000_000, 3)
     p = api.make_params(fixedstep=0, dt0=1e-3, dtmax=0.1, maxerr=5e-4, tmax=0.5, maxsteps=256, outputper=128, del_=1e-6,
@@ -273,6 +282,46 @@ def test_full_size_config3_interp256_1m():
     check_invariants(pos, rows, nrows, stop, steps, p)
     assert steps > 100_000_000
     idx = np.random.default_rng(6).choice(len(w), 8192, replace=False)
+    r2, n2, s2, _ = m.trace(pos[idx], d[idx], w[idx], params=p)
+    assert np.array_equal(r2, rows[idx]) and np.array_equal(n2, nrows[idx]) and np.array_equal(s2, stop[idx])
+
+
+def test_full_size_config4_interp_4m_shards(interp256_model):
+    """BASELINE config[3]: 4M rays (seed 4) on the 256^3 grid.  All 4M in one launch: properties; then the shard a rank of an
+    8-GPU run would get (parallel.shard_bounds(4M, 5, 8)) traced on its own, with the Morton-ordered schedule: bit-identical
+    to the same rays' results in the whole-set launch -- what makes the sharded run equal to the single-GPU one."""
+    from stanford_raytracer_amd import api, parallel
+
+    m = interp256_model
+    pos, d, w = wl.launch_set(4_000_000, 4)
+    p = api.make_params(fixedstep=0, dt0=1e-3, dtmax=0.1, maxerr=5e-4, tmax=0.5, maxsteps=256, outputper=128, del_=1e-6,
+                        minalt=wl.MINALT, ray_order=1)
+    rows, nrows, stop, steps = m.trace(pos, d, w, params=p)
+    check_invariants(pos, rows, nrows, stop, steps, p)
+    assert steps > 500_000_000
+    lo, hi = parallel.shard_bounds(4_000_000, 5, 8)
+    assert hi - lo == 500_000
+    r2, n2, s2, st2 = m.trace(pos[lo:hi], d[lo:hi], w[lo:hi], params=p)
+    assert np.array_equal(r2, rows[lo:hi]) and np.array_equal(n2, nrows[lo:hi]) and np.array_equal(s2, stop[lo:hi])
+    assert st2 == int(nrows[lo:hi].astype(np.int64).sum() - (hi - lo))
+
+
+def test_full_size_config5_scattered_1m(tmp_path):
+    """BASELINE config[4]: 1M rays (seed 5) against the 825 k-sample set of SURVEY 8d (200 k uniform + 600 k importance-
+    sampled + 25 k shell), maxsteps 64 -- properties only (one 24 s launch), and a shuffled subset bit for bit."""
+    from stanford_raytracer_amd import api
+
+    pts, lnN = wl.make_points_config5(5)
+    pf = str(tmp_path / "pts825k.bin")
+    api.write_points_file(pf, np.concatenate([pts, lnN], axis=1), np.array([-10.0 * wl.R_E, 10.0 * wl.R_E] * 3), wl.QS, wl.MS, binary=True)
+    m = api.Model.scattered_file(pf, window_scale=1.5, order=2, exact=0, local_window_scale=5.0)
+    pos, d, w = wl.launch_set(1_000_000, 5)
+    p = api.make_params(fixedstep=0, dt0=1e-3, dtmax=0.1, maxerr=5e-4, tmax=0.5, maxsteps=64, outputper=32, del_=1e-6,
+                        minalt=wl.MINALT)
+    rows, nrows, stop, steps = m.trace(pos, d, w, params=p)
+    check_invariants(pos, rows, nrows, stop, steps, p)
+    assert steps > 50_000_000
+    idx = np.random.default_rng(7).choice(len(w), 2048, replace=False)
     r2, n2, s2, _ = m.trace(pos[idx], d[idx], w[idx], params=p)
     assert np.array_equal(r2, rows[idx]) and np.array_equal(n2, nrows[idx]) and np.array_equal(s2, stop[idx])
     m.close()
