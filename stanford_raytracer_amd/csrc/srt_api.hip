@@ -82,7 +82,7 @@ extern "C" int srt_device_info(char *name, int name_len, int *cu_count, int64_t 
 // ------------------------------------------------------------------------------------------ model
 struct srt_model {
   int kind = 0, nspec = 0;
-  int device = 0; // the HIP device the tables live on
+  int device = current_device(); // the HIP device the tables live on (the creating thread's)
   Common cm{};
   NgoModel ngo{};
   InterpModel interp{};
@@ -171,6 +171,7 @@ static int model_finish(srt_model *m) {
 
 extern "C" void srt_model_destroy(srt_model *m) {
   if (!m) return;
+  (void)hipSetDevice(m->device); // its tables and events live there (the next entry point re-selects the caller's device)
   if (m->d_coef) (void)hipFree(m->d_coef);
   if (m->d_pts) (void)hipFree(m->d_pts);
   if (m->d_xyz) (void)hipFree(m->d_xyz);
