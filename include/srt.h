@@ -239,6 +239,12 @@ int srt_write_ray_file(const char *path, int append, int64_t raynum0, int64_t nr
                        const srt_params *p, int nspec, const double *qs, const double *ms,
                        const double *w0, const double *rows, const int32_t *nrows,
                        const int32_t *stopcond);
+/* .ray reader: the inverse of srt_write_ray_file, for files written by this library or by the reference's driver (what
+ * matlab/readrayoutput.m is to the MATLAB damping scripts): returns the number of rays (< 0: error) and malloc'd arrays
+ * (srt_free): raynum / stopcond / kept (records of the ray) / w0 per ray, rows[nrecords][SRT_ROW] = the kept rows of all rays
+ * back to back (the packed layout of srt_pack_rows_device), plus the record's constants nspec, qs, ms.  Host code, no GPU. */
+int64_t srt_read_ray_file(const char *path, int32_t *nspec, double qs[4], double ms[4], int64_t *nrecords,
+                          int64_t **raynum, int32_t **stopcond, int32_t **kept, double **w0, double **rows);
 void srt_free(void *p);
 
 /* model-3 grid files, the step before the path: the text format written by

@@ -104,6 +104,9 @@ def lib():
     L.srt_read_rays_file.restype = C.c_int64
     L.srt_write_ray_file.argtypes = [C.c_char_p, C.c_int, C.c_int64, C.c_int64, C.POINTER(Params), C.c_int, dp, dp,
                                      dp, dp, ip, ip]
+    L.srt_read_ray_file.argtypes = [C.c_char_p, ip, dp, dp, C.POINTER(C.c_int64), C.POINTER(C.POINTER(C.c_int64)), C.POINTER(ip),
+                                    C.POINTER(ip), C.POINTER(dp), C.POINTER(dp)]
+    L.srt_read_ray_file.restype = C.c_int64
     L.srt_free.argtypes = [vp]
     L.srt_free.restype = None
     L.srt_build_grid.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, dp, dp, dp]
@@ -386,6 +389,40 @@ def write_ray_file(path, species, params, w0, rows, nrows, stopcond, raynum0=1, 
     _check(lib().srt_write_ray_file(os.fsencode(path), int(append), raynum0, w0.shape[0], C.byref(params), nspec,
                                     _dp(qs), _dp(ms), _dp(w0), _dp(rows), nrows.ctypes.data_as(ip),
                                     stopcond.ctypes.data_as(ip)))
+
+
+def read_ray_file(path):
+    """A .ray file (this library's or the reference driver's) -> dict(raynum, stopcond, kept, w0 per ray; rows[nrecords, 20] =
+    the kept rows of all rays back to back; nspec, qs, ms).  `padded(slots)` rebuilds the [nrays, slots, 20] layout."""
+    nspec, nrec = C.c_int32(), C.c_int64()
+    qs, ms = np.zeros(4), np.zeros(4)
+    pr, ps, pk, pw, prow = C.POINTER(C.c_int64)(), ip(), ip(), dp(), dp()
+    n = lib().srt_read_ray_file(os.fsencode(path), C.byref(nspec), _dp(qs), _dp(ms), C.byref(nrec), C.byref(pr), C.byref(ps),
+                                C.byref(pk), C.byref(pw), C.byref(prow))
+    if n < 0:
+        _check(int(n))
+    try:
+        out = {"raynum": np.ctypeslib.as_array(pr, (n,)).copy() if n else np.zeros(0, dtype=np.int64),
+               "stopcond": np.ctypeslib.as_array(ps, (n,)).copy() if n else np.zeros(0, dtype=np.int32),
+               "kept": np.ctypeslib.as_array(pk, (n,)).copy() if n else np.zeros(0, dtype=np.int32),
+               "w0": np.ctypeslib.as_array(pw, (n,)).copy() if n else np.zeros(0),
+               "rows": np.ctypeslib.as_array(prow, (nrec.value, ROW)).copy() if nrec.value else np.zeros((0, ROW)),
+               "nspec": nspec.value, "qs": qs[:nspec.value].copy(), "ms": ms[:nspec.value].copy()}
+    finally:
+        for ptr in (pr, ps, pk, pw, prow):
+            lib().srt_free(ptr)
+    return out
+
+
+def padded_rows(ray):
+    """read_ray_file's packed rows -> (rows[nrays, slots, 20], nrows[nrays]) with slots = the longest ray (outputper = 1)."""
+    kept = ray["kept"]
+    n, slots = len(kept), int(kept.max()) if len(kept) else 1
+    rows = np.zeros((n, slots, ROW))
+    off = np.concatenate([[0], np.cumsum(kept)])
+    for i in range(n):
+        rows[i, :kept[i]] = ray["rows"][off[i]:off[i + 1]]
+    return rows, kept.astype(np.int32)
 
 
 # ---- model-3 grid files: text of the reference's grid builder <-> binary side-format (host code, no GPU) -------

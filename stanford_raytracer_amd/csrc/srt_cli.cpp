@@ -140,7 +140,8 @@ int main(int argc, char **argv) {
          "           accepts either form);  --pts2bin_in / --pts2bin_out: the same for model-4 sample files\n"
          "           --buildsamples=1 --filename=<out> --minx .. --maxz --n_initial_uniform ... (the reference's random grid\n"
          "           builder with the model of --modelnum in place of GCPM; --seed, --binary=1)\n"
-         "           --damping_out=<file>: hot-plasma damping along the kept rows (raynum, row, t, rate, magnitude, flag)");
+         "           --damping_out=<file>: hot-plasma damping along the kept rows (raynum, row, t, rate, magnitude, flag);\n"
+         "           with --damping_in=<.ray file> instead of tracing: along the records of an existing file");
     return 0;
   }
   {
@@ -197,6 +198,62 @@ int main(int argc, char **argv) {
              (long long)counts[1], (long long)counts[2], (long long)counts[3], (long long)counts[4], (long long)counts[5]);
       srt_free(rec);
       srt_model_destroy(m);
+      return 0;
+    }
+  }
+  {
+    // ours: --damping_in=<existing .ray file> --damping_out=<file>: the MATLAB post-processor (matlab/damping/test_dampray.m)
+    // on a file this program or the reference's driver wrote, without tracing anything
+    std::string din;
+    if (getopt_named("damping_in", din)) {
+      std::string dout;
+      need(getopt_named("damping_out", dout), "damping_out");
+      srt_damping_params dpar;
+      memset(&dpar, 0, sizeof dpar);
+      get_int("damping_dist", dpar.dist);
+      get_int("damping_mode", dpar.mode);
+      get_real("damping_Ne_h", dpar.Ne_h);
+      double kTeV = 0;
+      if (get_real("damping_kT_eV", kTeV)) dpar.kT = kTeV * 1.60217646e-19;
+      get_real("damping_tol", dpar.tol);
+      int device = 0;
+      get_int("device", device);
+      int32_t nspec = 0;
+      double qs[4], ms[4], *w0 = nullptr, *packed = nullptr;
+      int64_t nrec = 0, *raynum = nullptr;
+      int32_t *stop = nullptr, *kept = nullptr;
+      const int64_t n = srt_read_ray_file(din.c_str(), &nspec, qs, ms, &nrec, &raynum, &stop, &kept, &w0, &packed);
+      if (n < 0) {
+        fprintf(stderr, "raytracer: %s\n", srt_last_error());
+        return 1;
+      }
+      FILE *f = fopen(dout.c_str(), "w");
+      if (!f) {
+        fprintf(stderr, "raytracer: cannot open %s\n", dout.c_str());
+        return 1;
+      }
+      if (n > 0) {
+        CHECK(srt_init(device));
+        int slots = 1;
+        for (int64_t i = 0; i < n; ++i) slots = kept[i] > slots ? kept[i] : slots;
+        // the file's records are every row it kept: outputper = 1 with nrows = records of the ray
+        std::vector<double> rows((size_t)n * slots * SRT_ROW, 0.0), rate((size_t)n * slots), mag((size_t)n * slots);
+        std::vector<int32_t> flag((size_t)n * slots);
+        int64_t off = 0;
+        for (int64_t i = 0; i < n; ++i) {
+          memcpy(rows.data() + (size_t)i * slots * SRT_ROW, packed + (size_t)off * SRT_ROW, sizeof(double) * SRT_ROW * (size_t)kept[i]);
+          off += kept[i];
+        }
+        CHECK(srt_damping(&dpar, nspec, qs, ms, slots, 1, n, rows.data(), kept, w0, rate.data(), mag.data(), flag.data()));
+        for (int64_t i = 0; i < n; ++i)
+          for (int r = 0; r < kept[i]; ++r) {
+            const size_t idx = (size_t)i * slots + r;
+            fprintf(f, "%10lld%10d%25.15E%25.15E%25.15E%10d\n", (long long)raynum[i], r + 1, rows[idx * SRT_ROW], rate[idx], mag[idx], (int)flag[idx]);
+          }
+      }
+      fclose(f);
+      printf(" %lld rays, %lld records\n", (long long)n, (long long)nrec);
+      srt_free(raynum), srt_free(stop), srt_free(kept), srt_free(w0), srt_free(packed);
       return 0;
     }
   }

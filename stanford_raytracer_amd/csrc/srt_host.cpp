@@ -639,6 +639,74 @@ extern "C" int64_t srt_read_rays_file(const char *path, double **pos0, double **
   return n;
 }
 
+// .ray reader: the inverse of srt_write_ray_file (what matlab/readrayoutput.m does for the damping scripts).  Every record
+// is a run of blank-separated numbers -- 2 + 17 + 1 + 4 nspec of them -- so the whole file is parsed as one token stream by
+// all host cores and cut into records; the records of a ray are consecutive.
+extern "C" int64_t srt_read_ray_file(const char *path, int32_t *nspec_out, double qs[4], double ms[4], int64_t *nrecords,
+                                     int64_t **raynum, int32_t **stopcond, int32_t **kept, double **w0, double **rows) {
+  if (!path || !nspec_out || !qs || !ms || !nrecords || !raynum || !stopcond || !kept || !w0 || !rows)
+    return srt_set_error(SRT_EINVAL, "null argument");
+  *nspec_out = 0;
+  *nrecords = 0;
+  *raynum = nullptr, *stopcond = nullptr, *kept = nullptr, *w0 = nullptr, *rows = nullptr;
+  struct stat st;
+  if (stat(path, &st) != 0) return srt_set_error(SRT_EIO, "%s: cannot open", path);
+  std::vector<double> all;
+  std::string err;
+  if (st.st_size > 0 && !srt_host::read_all_numbers(path, all, err)) return srt_set_error(SRT_EIO, "%s: %s", path, err.c_str());
+  int64_t nrec = 0, nray = 0;
+  int nspec = 0;
+  if (!all.empty()) {
+    if (all.size() < 20) return srt_set_error(SRT_EIO, "%s: truncated record", path);
+    nspec = (int)all[19];
+    if (nspec < 1 || nspec > SRT_MAXSPEC || (double)nspec != all[19]) return srt_set_error(SRT_EIO, "%s: nspec = %g in the first record", path, all[19]);
+    const size_t per = 20 + (size_t)4 * nspec;
+    if (all.size() % per) return srt_set_error(SRT_EIO, "%s: %zu numbers are not a whole number of %zu-number records", path, all.size(), per);
+    nrec = (int64_t)(all.size() / per);
+    for (int64_t r = 0; r < nrec; ++r) {
+      const double *v = all.data() + (size_t)r * per;
+      if ((int)v[19] != nspec) return srt_set_error(SRT_EIO, "%s: record %lld has nspec %g", path, (long long)r + 1, v[19]);
+      if (r == 0 || v[0] != all[(size_t)(r - 1) * per]) ++nray;
+    }
+  }
+  const int64_t na = nray ? nray : 1, nr = nrec ? nrec : 1;
+  *raynum = (int64_t *)malloc(sizeof(int64_t) * na);
+  *stopcond = (int32_t *)malloc(sizeof(int32_t) * na);
+  *kept = (int32_t *)malloc(sizeof(int32_t) * na);
+  *w0 = (double *)malloc(sizeof(double) * na);
+  *rows = (double *)malloc(sizeof(double) * SRT_ROW * nr);
+  if (!*raynum || !*stopcond || !*kept || !*w0 || !*rows) {
+    free(*raynum), free(*stopcond), free(*kept), free(*w0), free(*rows);
+    *raynum = nullptr, *stopcond = nullptr, *kept = nullptr, *w0 = nullptr, *rows = nullptr;
+    return srt_set_error(SRT_ENOMEM, "%s: %lld records", path, (long long)nrec);
+  }
+  for (int s = 0; s < 4; ++s) qs[s] = ms[s] = 0.0;
+  const size_t per = 20 + (size_t)4 * (nspec ? nspec : 1);
+  int64_t ray = -1;
+  for (int64_t r = 0; r < nrec; ++r) {
+    const double *v = all.data() + (size_t)r * per;
+    if (r == 0 || v[0] != all[(size_t)(r - 1) * per]) {
+      ++ray;
+      (*raynum)[ray] = (int64_t)v[0];
+      (*stopcond)[ray] = (int32_t)v[1];
+      (*kept)[ray] = 0;
+      (*w0)[ray] = v[18];
+    }
+    (*kept)[ray] += 1;
+    double *row = *rows + (size_t)r * SRT_ROW;
+    for (int c = 0; c < 16; ++c) row[c] = v[2 + c]; // t, pos, vprel, vgrel, n, B0
+    for (int k = 0; k < 4; ++k) row[16 + k] = k < nspec ? v[20 + 2 * nspec + k] : 0.0; // Ns
+    if (r == 0)
+      for (int k = 0; k < nspec; ++k) {
+        qs[k] = v[20 + k];
+        ms[k] = v[20 + nspec + k];
+      }
+  }
+  *nspec_out = nspec;
+  *nrecords = nrec;
+  return nray;
+}
+
 // record format of raytracer_driver.f95:1197-1217:
 //   (i10, i10, 17es24.15e3, i10) raynum, stopcond, t, pos, vprel, vgrel, n, B0, w, nspec
 //   then nspec x es24.15e3 for each of qs, ms, Ns, nus

@@ -281,3 +281,27 @@ def test_cli_use_tsyganenko(tmp_path, cfgfiles):
     dip = api.Model.ngo(cfgfiles["ngo"]).plasma_params(x)[0, 16:19]
     got = np.array(row0[15:18])
     assert np.allclose(got, want, rtol=1e-14, atol=0) and np.abs(got - dip).max() > 1e-9
+
+
+def test_cli_damping_on_an_existing_ray_file(tmp_path):
+    """--damping_in=<.ray> --damping_out=<file>: the post-processor on a file the reference's own driver wrote
+    (tests/golden/driver_interp_adaptive.ray), no tracing: the same numbers as api.damping on the file's rows."""
+    from stanford_raytracer_amd import api
+
+    src = os.path.join(GOLDEN_DIR, "driver_interp_adaptive.ray")
+    out = tmp_path / "d.txt"
+    subprocess.run([os.path.join(BIN, "raytracer"), "--damping_in=%s" % src, "--damping_out=%s" % out], check=True)
+    r = api.read_ray_file(src)
+    rows, nrows = api.padded_rows(r)
+    k, m, f = api.damping((r["qs"], r["ms"]), 1, rows, nrows, r["w0"])
+    rec = np.loadtxt(str(out)).reshape(-1, 6)
+    assert len(rec) == nrows.sum()
+    i = 0
+    for ray in range(len(nrows)):
+        for s_ in range(nrows[ray]):
+            assert rec[i, 0] == r["raynum"][ray] and rec[i, 1] == s_ + 1 and rec[i, 5] == f[ray, s_]
+            assert rec[i, 2] == rows[ray, s_, 0]
+            assert np.isclose(rec[i, 3], k[ray, s_], rtol=1e-13, atol=0, equal_nan=True)
+            assert np.isclose(rec[i, 4], m[ray, s_], rtol=1e-13, atol=0, equal_nan=True)
+            i += 1
+    assert np.all(m[:, 0] == 1.0) and np.nanmin(m[np.arange(len(nrows)), nrows - 1]) < 1.0   # the rays do damp

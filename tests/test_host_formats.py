@@ -2,6 +2,7 @@
 import os
 
 import numpy as np
+import pytest
 
 from conftest import GOLDEN_DIR
 from stanford_raytracer_amd import api, workloads as wl
@@ -242,3 +243,49 @@ def test_points_file_text_layout_and_binary_side_format(tmp_path):
     # the oracle's reader (the adapter's READ statements restated) takes the text file
     o = oracle.Model.scattered_file(txt, order=1)
     assert o.nspec == 4
+
+
+def test_ray_file_reader(tmp_path, monkeypatch):
+    """srt_read_ray_file (the post-processor's way into an existing .ray file, matlab/readrayoutput.m's role): the reference
+    DRIVER's own files against a plain Python parse of the fixed-width records; then write -> read round trips exactly
+    what 16 significant digits hold, special values and an empty file included."""
+    from conftest import parse_ray_file
+
+    for name in ("driver_interp_adaptive.ray", "config1_outputper25.ray"):
+        path = os.path.join(GOLDEN_DIR, name)
+        ref = parse_ray_file(path)
+        r = api.read_ray_file(path)
+        assert r["nspec"] == 4 and len(r["rows"]) == len(ref) and r["kept"].sum() == len(ref)
+        assert np.array_equal(r["raynum"], np.arange(1, 17)) and np.array_equal(r["qs"], ref[0, 20:24]) and np.array_equal(r["ms"], ref[0, 24:28])
+        assert np.array_equal(r["rows"][:, 0:16], ref[:, 2:18]) and np.array_equal(r["rows"][:, 16:20], ref[:, 28:32])
+        first = np.concatenate([[0], np.cumsum(r["kept"])[:-1]])
+        assert np.array_equal(r["stopcond"], ref[first, 1].astype(np.int32)) and np.array_equal(r["w0"], ref[first, 18])
+        rows, nrows = api.padded_rows(r)
+        assert rows.shape == (16, r["kept"].max(), 20) and np.array_equal(rows[3, :nrows[3]], r["rows"][first[3]:first[3] + nrows[3]])
+    # round trip through the writer
+    rng = np.random.default_rng(3)
+    n, slots = 40, 6
+    p = api.make_params(maxsteps=6, outputper=1)
+    rows = rng.normal(size=(n, slots, 20)) * 10.0 ** rng.integers(-20, 20, size=(n, slots, 20))
+    rows[0, 0, 5], rows[1, 1, 6], rows[2, 0, 0] = np.nan, -np.inf, -0.0
+    nrows = rng.integers(1, 7, size=n).astype(np.int32)
+    stop = rng.integers(0, 7, size=n).astype(np.int32)
+    w0 = rng.uniform(1e3, 1e5, n)
+    out = tmp_path / "rt.ray"
+    api.write_ray_file(str(out), (4, wl.QS, wl.MS), p, w0, rows, nrows, stop, raynum0=7)
+    r = api.read_ray_file(str(out))
+    assert np.array_equal(r["raynum"], np.arange(7, 7 + n)) and np.array_equal(r["kept"], nrows) and np.array_equal(r["stopcond"], stop)
+    back, _ = api.padded_rows(r)
+    mask = np.arange(slots)[None, :] < nrows[:, None]
+    a, b = back[mask], rows[mask]
+    fin = np.isfinite(b)
+    assert np.allclose(a[fin], b[fin], rtol=6e-16, atol=0) and np.array_equal(np.isnan(a), np.isnan(b))
+    assert np.array_equal(a[~fin & ~np.isnan(b)], b[~fin & ~np.isnan(b)])
+    assert np.allclose(r["w0"], w0, rtol=6e-16, atol=0) and np.allclose(r["qs"], wl.QS, rtol=6e-16) and np.allclose(r["ms"], wl.MS, rtol=6e-16)
+    api.write_ray_file(str(out), (4, wl.QS, wl.MS), p, w0[:0], rows[:0], nrows[:0], stop[:0])
+    e = api.read_ray_file(str(out))
+    assert len(e["raynum"]) == 0 and e["rows"].shape == (0, 20)
+    bad = tmp_path / "bad.ray"
+    bad.write_text(open(os.path.join(GOLDEN_DIR, "config1_outputper25.ray")).read()[:-400])     # a truncated last record
+    with pytest.raises(api.SrtError):
+        api.read_ray_file(str(bad))
