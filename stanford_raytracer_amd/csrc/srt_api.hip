@@ -1188,9 +1188,23 @@ extern "C" int srt_trace_batch_device(srt_model *m, const srt_params *p, int64_t
   a.order = nullptr;
   HIP_OK(hipMemsetAsync(d_counters, 0, 4 * sizeof(int64_t), st));
   // persistent grid: enough one-wave blocks to fill the chip, never more than the rays need
-  long long want = (nrays + WAVE - 1) / WAVE;
   int per_cu = (m->kind == 3 || m->kind == 4) ? 4 : 8; // interp / scattered: 34 KiB of LDS per wave, 512 registers per lane
+  if (const char *e = getenv("SRT_WAVES_PER_CU")) {
+    const int v = atoi(e);
+    if (v >= 1 && v <= per_cu) per_cu = v;
+  }
   long long grid = (long long)m->cu_count * per_cu;
+  // Rays a wave holds at most.  64 = every lane.  (Measured for the Ngo model, whose launch at BASELINE config[1] is as long as
+  // its longest ray: with at most 8 rays per wave every trip runs in tail mode -- the 8 stencil points of a ray on 8 lanes,
+  // srt_models.hpp -- but a tail-mode trip is only 2.2x shorter than a full one while serving 8x fewer rays: 47.5 -> 51.6 ms.
+  // SRT_WAVE_CAP / SRT_WAVES_PER_CU remain as experiment switches; a ray's arithmetic does not depend on either.)
+  int cap = WAVE;
+  if (const char *e = getenv("SRT_WAVE_CAP")) {
+    const int v = atoi(e);
+    if (v >= 1 && v <= WAVE) cap = v;
+  }
+  a.p.wave_cap = cap;
+  long long want = (nrays + cap - 1) / cap;
   if (grid > want) grid = want;
   if (grid < 1) grid = 1;
   srt_model::LaunchSlot &sl = m->slot[m->next_slot];

@@ -15,17 +15,18 @@ namespace srt {
 // 2 end-point stencil densities, 3 error term, 4 root re-projection, 5 end-point right-hand side, 6 bookkeeping, 7 trips,
 // 8 trips with <= 8 active lanes, 9 loop top (stop tests, refill), 10 stage bookkeeping.
 #ifdef SRT_TRIP_TIMING
-__device__ unsigned long long srt_trip_cycles[16];
-#define SRT_TT_BEGIN() unsigned long long tt0_ = __builtin_readcyclecounter()
+#define SRT_TT_BEGIN() __builtin_amdgcn_sched_barrier(0); unsigned long long tt0_ = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0)
 #define SRT_TT(slot)                                                                                   \
   do {                                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
     unsigned long long tt1_ = __builtin_readcyclecounter();                                            \
-    if (threadIdx.x == 0) atomicAdd(&srt_trip_cycles[slot], tt1_ - tt0_);           \
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
+    if (threadIdx.x == 0) srt_tt_lds()[slot] += tt1_ - tt0_;                        \
     tt0_ = tt1_;                                                                                       \
   } while (0)
 #define SRT_TT_COUNT(slot, v)                                                                          \
   do {                                                                                                 \
-    if (threadIdx.x == 0) atomicAdd(&srt_trip_cycles[slot], (unsigned long long)(v)); \
+    if (threadIdx.x == 0) srt_tt_lds()[slot] += (unsigned long long)(v);              \
   } while (0)
 #else
 #define SRT_TT_BEGIN() do {} while (0)
@@ -37,6 +38,7 @@ struct TraceParams {
   double dt0, dtmax, tmax, maxerr, minalt, del;
   int maxsteps, root, fixedstep, outputper, first_attempt_policy, refill_threshold;
   int slots;
+  int wave_cap; // rays a wave holds at most (64 = every lane; 8 = every trip runs in the Ngo model's tail mode, see srt_api.hip)
 };
 
 struct TraceArgs {
@@ -277,6 +279,10 @@ __global__ __launch_bounds__(64) void trace_kernel(const M *__restrict__ mp, con
   bool first_attempt = true;
   unsigned long long acc_steps = 0, acc_attempts = 0, wave_trips = 0;
   const int threshold = P.refill_threshold > 0 ? P.refill_threshold : 1;
+#ifdef SRT_TRIP_TIMING
+  if (threadIdx.x < 16) srt_tt_lds()[threadIdx.x] = 0ull;
+  __syncthreads();
+#endif
   SRT_TT_BEGIN();
 
   for (;;) {
@@ -298,14 +304,16 @@ __global__ __launch_bounds__(64) void trace_kernel(const M *__restrict__ mp, con
     // ---- B. refill free lanes from the queue (ballot compaction)
     unsigned long long freemask = __ballot(!active);
     int nfree = __popcll(freemask);
-    if (!queue_empty && (nfree >= threshold || nfree == WAVE)) {
+    const int room = P.wave_cap - (WAVE - nfree);      // a wave holds at most wave_cap rays
+    const int take = nfree < room ? nfree : (room > 0 ? room : 0);
+    if (!queue_empty && take > 0 && (nfree >= threshold || nfree == WAVE)) {
       unsigned long long base = 0;
-      if (lane == 0) base = atomicAdd(a.counters, (unsigned long long)nfree);
+      if (lane == 0) base = atomicAdd(a.counters, (unsigned long long)take);
       base = __shfl(base, 0);
       if (!active) {
         int rank = __popcll(freemask & ((1ull << lane) - 1ull));
         long long id = (long long)base + rank;
-        if (id < a.nrays) {
+        if (rank < take && id < a.nrays) {
           if (a.order) id = a.order[id];
           ray = id;
           needinit = true;
@@ -318,7 +326,7 @@ __global__ __launch_bounds__(64) void trace_kernel(const M *__restrict__ mp, con
           w = a.w0[id];
         }
       }
-      if ((long long)base + nfree >= a.nrays) queue_empty = true;
+      if ((long long)base + take >= a.nrays) queue_empty = true;
     }
     // ---- C. (newly claimed rays have no step of their own this trip: they ride along with the running ones and
     // their launch point takes the place of the step's end point in E/F/G, see there; :661-742.  Every ray is
@@ -554,6 +562,10 @@ __global__ __launch_bounds__(64) void trace_kernel(const M *__restrict__ mp, con
     }
     SRT_TT(6);
   }
+#ifdef SRT_TRIP_TIMING
+  __syncthreads();
+  if (threadIdx.x < 16) atomicAdd(&srt_trip_cycles[threadIdx.x], srt_tt_lds()[threadIdx.x]);
+#endif
   // per-wave totals
   for (int off = 32; off > 0; off >>= 1) {
     acc_steps += __shfl_down(acc_steps, off);

@@ -20,6 +20,15 @@ constexpr int TILE_PAD_BYTES = 2048;
 constexpr int TILE_DOUBLES = (RING * UNIT_BYTES + TILE_PAD_BYTES) / 8;
 
 typedef double d2_t __attribute__((ext_vector_type(2)));
+#ifdef SRT_TRIP_TIMING
+__device__ unsigned long long srt_trip_cycles[16]; // see srt_kernels.hpp
+// per-wave sums live in LDS and are flushed once at the end of the kernel: a global atomic per mark would itself show up in
+// whatever waits on memory next (every wave adding to the same 16 words)
+__device__ __forceinline__ unsigned long long *srt_tt_lds() {
+  __shared__ unsigned long long acc[16];
+  return acc;
+}
+#endif
 
 // Per-launch device scratch of a model (only the scattered model has any: srt_scattered.hpp overloads this).
 template <class M>
@@ -181,6 +190,12 @@ struct NgoModel {
     const unsigned long long needy = __ballot(need);
     const int nneedy = __popcll(needy);
     if (nneedy >= 1 && nneedy <= 8) { // wave-uniform
+#ifdef SRT_TRIP_TIMING
+      __builtin_amdgcn_sched_barrier(0); unsigned long long tt0_ = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0);
+#define SRT_TTM(slot_) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t1_ = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0) srt_tt_lds()[slot_] += t1_ - tt0_; tt0_ = t1_; } while (0)
+#else
+#define SRT_TTM(slot_) do {} while (0)
+#endif
       const int lane = (int)__lane_id(), slot = lane >> 3, pt = lane & 7;
       unsigned long long mask = needy;
       for (int k = 0; k < slot && mask; ++k) mask &= mask - 1; // drop the `slot` lowest needy lanes
@@ -195,17 +210,31 @@ struct NgoModel {
         v = (NE && pt == 7) ? oe : v;
         q[a] = v;
       }
+      SRT_TTM(11);
       double mine[4];
       dens_point(q[0], q[1], q[2], mine);
-      // rank of this lane among the needy ones = the slot that served it
+      SRT_TTM(12);
+      // rank of this lane among the needy ones = the slot that served it.  Unconditional assignments: lanes that asked for
+      // nothing receive some other ray's numbers, which nothing reads (a conditional assignment here becomes one exec-mask
+      // branch per value, each behind its own wait for the cross-lane read: 32 of them cost 15x the density evaluation itself)
       const int rank = __popcll(needy & ((1ull << lane) - 1ull));
+      // hand-off through LDS: every lane parks its four densities (32 B), the owners read their 7-8 points back as 128-bit
+      // words -- 16 LDS reads instead of 64 per-lane-indexed cross-lane reads (ds_bpermute)
+      __shared__ __attribute__((aligned(16))) double park[WAVE * 4];
+      {
+        d2_t *mp_ = (d2_t *)(park + 4 * lane);
+        mp_[0] = d2_t{mine[0], mine[1]};
+        mp_[1] = d2_t{mine[2], mine[3]};
+      }
+      __syncthreads(); // block == one wave
 #pragma unroll
-      for (int i = 0; i < 7 + NE; ++i)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const double v = __shfl(mine[s], 8 * rank + i);
-          if (need) Ns[i][s] = v;
-        }
+      for (int i = 0; i < 7 + NE; ++i) {
+        const d2_t *src = (const d2_t *)(park + 4 * ((8 * rank + i) & 63));
+        const d2_t a = src[0], b = src[1];
+        Ns[i][0] = a.x, Ns[i][1] = a.y, Ns[i][2] = b.x, Ns[i][3] = b.y;
+      }
+      __syncthreads(); // the next round overwrites the slots
+      SRT_TTM(13);
       return;
     }
     dens_point(c[0], c[1], c[2], Ns[0]);
