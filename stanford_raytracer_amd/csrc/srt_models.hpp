@@ -178,75 +178,158 @@ struct NgoModel {
 #pragma unroll
     for (int i = 0; i < NP; ++i) dens_point(p[i][0], p[i][1], p[i][2], Ns[i]);
   }
+  // Two points per call, ONE compiled body (noinline) for every path of the trace kernel: a single density evaluation is one
+  // dependent chain of exp / pow / division steps (measured 7.7 cycles per instruction with one wave per SIMD); two
+  // independent chains in one body interleave.  Point i of a stencil always goes through half (i & 1) of the pair, whichever
+  // path and lane evaluates it, so a ray's arithmetic does not depend on either.
+  struct Dens2 {
+    double a[4], b[4];
+  };
+  __device__ __noinline__ Dens2 dens_pair(double ax, double ay, double az, double bx, double by, double bz) const {
+    Dens2 r;
+    const double rhoa = ax * ax + ay * ay, ra2 = rhoa + az * az, ra = sqrt(ra2);
+    const double rhob = bx * bx + by * by, rb2 = rhob + bz * bz, rb = sqrt(rb2);
+    const double z1[2] = {r0 * ra / R_E, r0 * rb / R_E}, s2[2] = {rhoa / ra2, rhob / rb2}, lat[2] = {az, bz};
+    double N[2][4];
+    dens_core2(z1, s2, lat, N);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) r.a[s] = N[0][s], r.b[s] = N[1][s];
+    return r;
+  }
+  // dens_core for two points, statement by statement, so that the two dependent chains sit in the same basic blocks and
+  // interleave: the plasmapause term (taken when deltal >= 0 in the Fortran, :218-239) is evaluated for both points and
+  // selected -- the same values as the branch gives.  The operations and their order per point are those of dens_core.
+  __device__ __forceinline__ void dens_core2(const double (&z1)[2], const double (&sinz22)[2], const double (&latitu)[2], double (&Ns)[2][4]) const {
+    const double rb7370 = rbase / 7370.0;
+    const double sh2 = (double)1.150600f * therm * rb7370 * rb7370;
+    double q2[2], q3[2], q4[2], q[2], ani1[2], l[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const double gph = rbase * (1.0 - rbase / z1[p]);
+      const double e2 = exp(-gph / sh2);
+      const double e3 = e2 * e2 * e2 * e2;
+      const double e4 = e3 * e3 * e3 * e3;
+      q2[p] = alpha0[2] * e2, q3[p] = (num >= 3) ? alpha0[3] * e3 : 0.0, q4[p] = (num >= 4) ? alpha0[4] * e4 : 0.0;
+      q[p] = q2[p] + q3[p] + q4[p];
+      const double anr = sqrt(q[p]);
+      double arg = (z1[p] - rzero) / scbot;
+      if (!(arg < 13.0)) arg = 13.0;
+      const double anli = 1.0 - exp(-arg * arg);
+      l[p] = z1[p] / (r0 * sinz22[p]);
+      ani1[p] = ane0 * anr * anli;
+    }
+    if (kducts != 0) { // wave-uniform
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const double deltal = l[p] - lk;
+        const double d2 = ddk * ddk;
+        double argl = deltal * deltal / (d2 * 2.0);
+        if (!(argl < 80.0)) argl = 80.0;
+        const double f = exp(-argl);
+        const double trm = pow(rconsn / z1[p], expk);
+        double argr = (z1[p] - rconsn) / scr;
+        if (!(argr < 12.5)) argr = 12.5;
+        const double fr = exp(-argr * argr);
+        const double trmodl = trm + (1.0 - trm) * fr;
+        const double with_pp = ani1[p] * (f + trmodl * (1.0 - f));
+        ani1[p] = !(deltal < 0.0) ? with_pp : ani1[p]; // plasmapause (:218-239)
+      }
+      if (kducts != 1) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) ani1[p] *= ducts(l[p], z1[p], latitu[p]);
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const double invq = 1.0 / q[p];
+      Ns[p][0] = 1.0e6 * ani1[p];
+      Ns[p][1] = 1.0e6 * (ani1[p] * (q2[p] * invq));
+      Ns[p][2] = 1.0e6 * (ani1[p] * (q3[p] * invq));
+      Ns[p][3] = 1.0e6 * (ani1[p] * (q4[p] * invq));
+    }
+  }
+  // point i of the stencil (0 centre, 1 + 2a / 2 + 2a = +- d_a along axis a, 7 = the free point or, without one, the centre again)
+  template <int NE>
+  __device__ __forceinline__ static void stencil_point(int i, const double oc[3], const double od[3], const double oe[3], double q[3]) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      double v = oc[a];
+      v = (i == 1 + 2 * a) ? oc[a] + od[a] : v;
+      v = (i == 2 + 2 * a) ? oc[a] - od[a] : v;
+      v = (NE && i == 7) ? oe[a] : v;
+      q[a] = v;
+    }
+  }
   // Stencil of one right-hand side: centre, centre +- d_a e_a, optionally one free point.  All 64 lanes call together.
   // Tail mode: a launch ends with a few long rays (config[1]: 27 of 100 k rays run to maxsteps while the mean ray
-  // stops after 29 steps), one per wave, each doing its 7-8 density evaluations one after the other while 56+ lanes
-  // idle.  When at most 8 lanes of the wave need a stencil, the k-th needy lane's points are spread over lanes
-  // 8k .. 8k+7 -- one dens_point per lane instead of eight in a row -- and the results shuffled back.  Same function,
-  // same arguments, another lane: bit-identical results.
+  // stops after 29 steps), each doing its 7-8 density evaluations one after the other while most lanes idle.  When at most
+  // 16 lanes of the wave need a stencil, the k-th needy lane's points are spread over lanes 4k .. 4k+3 -- one dens_pair per lane
+  // instead of four in a row -- and handed back through LDS.  Same function, same arguments, another lane: bit-identical
+  // results.
   template <int NE>
   __device__ __forceinline__ void density_stencil(const double c[3], const double d[3], const double *extra,
                                                   double (&Ns)[7 + NE][4], double *, bool need = true) const {
     const unsigned long long needy = __ballot(need);
     const int nneedy = __popcll(needy);
-    if (nneedy >= 1 && nneedy <= 8) { // wave-uniform
+    if (nneedy >= 1 && nneedy <= 16) { // wave-uniform
 #ifdef SRT_TRIP_TIMING
       __builtin_amdgcn_sched_barrier(0); unsigned long long tt0_ = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0);
 #define SRT_TTM(slot_) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t1_ = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0) srt_tt_lds()[slot_] += t1_ - tt0_; tt0_ = t1_; } while (0)
 #else
 #define SRT_TTM(slot_) do {} while (0)
 #endif
-      const int lane = (int)__lane_id(), slot = lane >> 3, pt = lane & 7;
+      const int lane = (int)__lane_id(), slot = lane >> 2, sub = lane & 3;
       unsigned long long mask = needy;
       for (int k = 0; k < slot && mask; ++k) mask &= mask - 1; // drop the `slot` lowest needy lanes
       const int owner = (slot < nneedy) ? __builtin_ctzll(mask) : lane;
-      double q[3];
+      double oc[3], od[3], oe[3], qa[3], qb[3];
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
-        const double oc = __shfl(c[a], owner), od = __shfl(d[a], owner), oe = NE ? __shfl(extra[a], owner) : 0.0;
-        double v = oc;
-        v = (pt == 1 + 2 * a) ? oc + od : v;
-        v = (pt == 2 + 2 * a) ? oc - od : v;
-        v = (NE && pt == 7) ? oe : v;
-        q[a] = v;
+        oc[a] = __shfl(c[a], owner);
+        od[a] = __shfl(d[a], owner);
+        oe[a] = NE ? __shfl(extra[a], owner) : 0.0;
       }
+      stencil_point<NE>(2 * sub, oc, od, oe, qa);
+      stencil_point<NE>(2 * sub + 1, oc, od, oe, qb);
       SRT_TTM(11);
-      double mine[4];
-      dens_point(q[0], q[1], q[2], mine);
+      const Dens2 mine = dens_pair(qa[0], qa[1], qa[2], qb[0], qb[1], qb[2]);
       SRT_TTM(12);
-      // rank of this lane among the needy ones = the slot that served it.  Unconditional assignments: lanes that asked for
-      // nothing receive some other ray's numbers, which nothing reads (a conditional assignment here becomes one exec-mask
-      // branch per value, each behind its own wait for the cross-lane read: 32 of them cost 15x the density evaluation itself)
-      const int rank = __popcll(needy & ((1ull << lane) - 1ull));
-      // hand-off through LDS: every lane parks its four densities (32 B), the owners read their 7-8 points back as 128-bit
-      // words -- 16 LDS reads instead of 64 per-lane-indexed cross-lane reads (ds_bpermute)
-      __shared__ __attribute__((aligned(16))) double park[WAVE * 4];
+      // hand-off through LDS: every lane parks its two points' densities (64 B), the owners read their 7-8 points back as
+      // 128-bit words -- 16 LDS reads; per-lane-indexed cross-lane reads (64 ds_bpermute) measured 7 % slower on the launch,
+      // and behind a conditional assignment (one exec-mask branch per value) 15 % slower
+      const int rank = __popcll(needy & ((1ull << lane) - 1ull)); // this lane's slot if it is an owner
+      __shared__ __attribute__((aligned(16))) double park[WAVE * 8];
       {
-        d2_t *mp_ = (d2_t *)(park + 4 * lane);
-        mp_[0] = d2_t{mine[0], mine[1]};
-        mp_[1] = d2_t{mine[2], mine[3]};
+        d2_t *mp_ = (d2_t *)(park + 8 * lane);
+        mp_[0] = d2_t{mine.a[0], mine.a[1]};
+        mp_[1] = d2_t{mine.a[2], mine.a[3]};
+        mp_[2] = d2_t{mine.b[0], mine.b[1]};
+        mp_[3] = d2_t{mine.b[2], mine.b[3]};
       }
       __syncthreads(); // block == one wave
 #pragma unroll
       for (int i = 0; i < 7 + NE; ++i) {
-        const d2_t *src = (const d2_t *)(park + 4 * ((8 * rank + i) & 63));
-        const d2_t a = src[0], b = src[1];
-        Ns[i][0] = a.x, Ns[i][1] = a.y, Ns[i][2] = b.x, Ns[i][3] = b.y;
+        const d2_t *src = (const d2_t *)(park + 8 * ((4 * rank + (i >> 1)) & 63) + 4 * (i & 1));
+        const d2_t u = src[0], v = src[1];
+        Ns[i][0] = u.x, Ns[i][1] = u.y, Ns[i][2] = v.x, Ns[i][3] = v.y;
       }
       __syncthreads(); // the next round overwrites the slots
       SRT_TTM(13);
       return;
     }
-    dens_point(c[0], c[1], c[2], Ns[0]);
+    const double oe[3] = {NE ? extra[0] : 0.0, NE ? extra[1] : 0.0, NE ? extra[2] : 0.0};
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      double pp[3] = {c[0], c[1], c[2]}, pm[3] = {c[0], c[1], c[2]};
-      pp[a] = c[a] + d[a];
-      pm[a] = c[a] - d[a];
-      dens_point(pp[0], pp[1], pp[2], Ns[1 + 2 * a]);
-      dens_point(pm[0], pm[1], pm[2], Ns[2 + 2 * a]);
+    for (int h = 0; h < 4; ++h) {
+      double qa[3], qb[3];
+      stencil_point<NE>(2 * h, c, d, oe, qa);
+      stencil_point<NE>(2 * h + 1, c, d, oe, qb);
+      const Dens2 r = dens_pair(qa[0], qa[1], qa[2], qb[0], qb[1], qb[2]);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        Ns[2 * h][s] = r.a[s];
+        if (2 * h + 1 < 7 + NE) Ns[2 * h + 1][s] = r.b[s];
+      }
     }
-    if (NE) dens_point(extra[0], extra[1], extra[2], Ns[7 + NE - 1]);
   }
 };
 
