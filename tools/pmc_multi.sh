@@ -7,6 +7,6 @@ i=0
 while read -r CNT; do
   [ -z "$CNT" ] && continue
   i=$((i+1))
-  timeout -k 10 300 rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d $O/p$i -- python3 bench.py --steps 1 --warmup 0 --cpu-seconds 0 "$@" > $O/p$i.log 2>&1
+  timeout -k 10 300 rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d $O/p$i -- python3 bench.py --traffic off --other-configs 0 --steps 1 --warmup 0 --cpu-seconds 0 "$@" > $O/p$i.log 2>&1
   grep -h trace_kernel $O/p$i/*/*counter_collection.csv | awk -F, '{print $(NF-3), $(NF-2)}' | sed 's/"//g'
 done < $R/tools/pmc_sets.txt
