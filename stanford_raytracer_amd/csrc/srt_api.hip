@@ -112,7 +112,27 @@ struct srt_model {
   static constexpr int NSLOT = 4;
   LaunchSlot slot[NSLOT];
   int next_slot = 0, last_slot = -1;
+  // device staging of the host-buffer entry point srt_trace_batch (grow-only, freed with the model): the CLI calls it
+  // once per chunk of the ray file, and a fresh hipMalloc / hipFree of gigabytes per call costs as much as a small launch
+  struct HostIO {
+    void *p[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t cap[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  } io;
 };
+static int io_reserve(srt_model *m, int k, size_t bytes, void **out) {
+  if (bytes > m->io.cap[k]) {
+    if (m->io.p[k]) (void)hipFree(m->io.p[k]);
+    m->io.p[k] = nullptr;
+    m->io.cap[k] = 0;
+    if (hipMalloc(&m->io.p[k], bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      return srt_set_error(SRT_ENOMEM, "hipMalloc of %zu bytes failed", bytes);
+    }
+    m->io.cap[k] = bytes;
+  }
+  *out = m->io.p[k];
+  return SRT_OK;
+}
 
 // switch the calling thread to the model's device
 static int ensure_model(const srt_model *m) {
@@ -188,6 +208,8 @@ extern "C" void srt_model_destroy(srt_model *m) {
     if (sl.ev1) (void)hipEventDestroy(sl.ev1);
   }
   if (m->d_common) (void)hipFree(m->d_common);
+  for (void *q : m->io.p)
+    if (q) (void)hipFree(q);
   delete m;
 }
 // use_igrf (raytracer_driver.f95 --use_igrf; interp_dens_model_adapter.f95:236-241 and twins)
@@ -1501,28 +1523,25 @@ extern "C" int srt_trace_batch(srt_model *m, const srt_params *p, int64_t nrays,
   if ((rc = ensure_model(m))) return rc;
   const int slots = srt_rows_per_ray(p);
   const size_t nrow_d = (size_t)nrays * slots * SRT_ROW;
-  DevBuf a_pos, a_dir, s_pos, s_dir, dw, drows;
-  if ((rc = upload(a_pos, pos0, 3 * nrays)) || (rc = upload(a_dir, dir0, 3 * nrays)) || (rc = upload(dw, w0, nrays))) return rc;
-  if (s_pos.alloc(3 * nrays) || s_dir.alloc(3 * nrays) || drows.alloc(nrow_d)) return srt_set_error(SRT_ENOMEM, "hipMalloc failed (rows: %zu bytes)", nrow_d * 8);
-  int32_t *d_n = nullptr, *d_s = nullptr;
-  int64_t *d_c = nullptr;
-  auto freeall = [&]() {
-    if (d_n) (void)hipFree(d_n);
-    if (d_s) (void)hipFree(d_s);
-    if (d_c) (void)hipFree(d_c);
-  };
-  if (hipMalloc(&d_n, nrays * sizeof(int32_t)) != hipSuccess || hipMalloc(&d_s, nrays * sizeof(int32_t)) != hipSuccess ||
-      hipMalloc(&d_c, 4 * sizeof(int64_t)) != hipSuccess) {
-    freeall();
-    return srt_set_error(SRT_ENOMEM, "hipMalloc failed");
-  }
+  double *a_pos, *a_dir, *s_pos, *s_dir, *dw, *drows;
+  int32_t *d_n, *d_s;
+  int64_t *d_c;
+  const size_t v3 = (size_t)3 * nrays * sizeof(double);
+  if ((rc = io_reserve(m, 0, v3, (void **)&a_pos)) || (rc = io_reserve(m, 1, v3, (void **)&a_dir)) || (rc = io_reserve(m, 2, v3, (void **)&s_pos)) ||
+      (rc = io_reserve(m, 3, v3, (void **)&s_dir)) || (rc = io_reserve(m, 4, (size_t)nrays * sizeof(double), (void **)&dw)) ||
+      (rc = io_reserve(m, 5, nrow_d * sizeof(double), (void **)&drows)) || (rc = io_reserve(m, 6, (size_t)nrays * sizeof(int32_t), (void **)&d_n)) ||
+      (rc = io_reserve(m, 7, (size_t)nrays * sizeof(int32_t), (void **)&d_s)) || (rc = io_reserve(m, 8, 4 * sizeof(int64_t), (void **)&d_c)))
+    return rc;
+  HIP_OK(hipMemcpy(a_pos, pos0, v3, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(a_dir, dir0, v3, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(dw, w0, (size_t)nrays * sizeof(double), hipMemcpyHostToDevice));
   unsigned blocks = (unsigned)((nrays + 255) / 256);
-  hipLaunchKernelGGL(aos_to_soa3, dim3(blocks), dim3(256), 0, 0, (const double *)a_pos.p, s_pos.p, (long long)nrays);
-  hipLaunchKernelGGL(aos_to_soa3, dim3(blocks), dim3(256), 0, 0, (const double *)a_dir.p, s_dir.p, (long long)nrays);
-  (void)hipMemsetAsync(drows.p, 0, nrow_d * sizeof(double), 0);
-  rc = srt_trace_batch_device(m, p, nrays, s_pos.p, s_dir.p, dw.p, drows.p, d_n, d_s, d_c, nullptr);
+  hipLaunchKernelGGL(aos_to_soa3, dim3(blocks), dim3(256), 0, 0, (const double *)a_pos, s_pos, (long long)nrays);
+  hipLaunchKernelGGL(aos_to_soa3, dim3(blocks), dim3(256), 0, 0, (const double *)a_dir, s_dir, (long long)nrays);
+  (void)hipMemsetAsync(drows, 0, nrow_d * sizeof(double), 0);
+  rc = srt_trace_batch_device(m, p, nrays, s_pos, s_dir, dw, drows, d_n, d_s, d_c, nullptr);
   if (rc == SRT_OK) {
-    hipError_t e = hipMemcpy(rows, drows.p, nrow_d * sizeof(double), hipMemcpyDeviceToHost);
+    hipError_t e = hipMemcpy(rows, drows, nrow_d * sizeof(double), hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(nrows, d_n, nrays * sizeof(int32_t), hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(stopcond, d_s, nrays * sizeof(int32_t), hipMemcpyDeviceToHost);
     int64_t c[4] = {0, 0, 0, 0};
@@ -1530,6 +1549,5 @@ extern "C" int srt_trace_batch(srt_model *m, const srt_params *p, int64_t nrays,
     if (e != hipSuccess) rc = srt_set_error(SRT_EDEVICE, "trace kernel failed: %s", hipGetErrorString(e));
     else if (accepted_steps) *accepted_steps = c[1];
   }
-  freeall();
   return rc;
 }
