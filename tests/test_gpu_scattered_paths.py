@@ -188,3 +188,30 @@ def test_order3_both_paths_and_a_short_trace(pointsfile):
     assert np.mean(stop == ostop) >= 0.9
     assert np.median(vrel(rows[both, 1, 1:4], orows[both, 1, 1:4])) <= 1e-6
     assert abs(int(nrows.sum()) - int(onrows.sum())) <= 0.25 * onrows.sum()
+
+
+@pytest.mark.parametrize("order", [0, 1])
+def test_orders_0_and_1_through_both_paths(pointsfile, order):
+    """--scattered_interp_order=0 / 1 (J = 1 / 4): the cooperative stencil's shared and own-list paths and the per-lane
+    evaluation against the CPU oracle (order 0 is a weighted mean: its gradient comes from the weights alone)."""
+    from oracle import oracle
+    from stanford_raytracer_amd import api, workloads as wl
+
+    g = api.Model.scattered_file(pointsfile, order=order)
+    o = oracle.Model.scattered_file(pointsfile, perm_seed=2 | 0x80000000, order=order)
+    pos, _, _ = wl.launch_set(200, 321)
+    pos = pos * 0.9
+    gp = g.plasma_params(pos)
+    op = np.array([np.concatenate(o.plasma_params(p)) for p in pos])
+    ok = op[:, 4] > 0
+    assert (np.abs(gp[ok, 4:8] - op[ok, 4:8]) / op[ok, 4:8]).max() <= 1e-9
+    x, k, w = _states(o, 300, 4321)
+    x, k, w = x[:80], k[:80], w[:80]
+    a = g.gradients(x, k, w, 1e-6)
+    b = _own_list(lambda: g.gradients(x, k, w, 1e-6))
+    og = np.array([o.grad(p, kk, ww, 1e-6) for p, kk, ww in zip(x, k, w)])
+    assert np.isfinite(a).all() and np.isfinite(b).all()
+    assert vrel(a[:, 0:3], og[:, 0:3]).max() <= 1e-7 and vrel(a[:, 0:3], b[:, 0:3]).max() <= 1e-9
+    for other in (b, og):
+        e = vrel(a[:, 4:7], other[:, 4:7])
+        assert np.median(e) <= 1e-5 and np.percentile(e, 90) <= 1e-3
