@@ -120,3 +120,44 @@ def test_gpu_igrf_adaptive_step_control_matches_the_oracle(cfgfiles):
     # and twice the same answer
     rows2, nrows2, _, _ = g.trace(pos, d, w, outputper=1, **kw)
     assert np.array_equal(nrows, nrows2) and np.array_equal(np.nan_to_num(rows), np.nan_to_num(rows2))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["interp", "scattered"])
+def test_gpu_igrf_with_the_table_models(grid16, pointsfile, name):
+    """use_igrf = 1 with modelnum 3 and 4 (interp_dens_model_adapter.f95:236-241 and its twin in the scattered adapter):
+    the trace kernels that combine the IGRF synthesis (coefficient terms spread over the wave's registers) with the LDS
+    coefficient ring / the cooperative stencil.  Against the oracle with the same field: the row-0 field, the first
+    controller decisions, stop codes, row totals -- the bars of the Ngo test above -- and run-to-run bit identity."""
+    from oracle import oracle
+    from stanford_raytracer_amd import api
+    api.init(0)
+    F, b, qs, ms_ = grid16
+    if name == "interp":
+        g = api.Model.interp(F, b, qs, ms_)
+        o = oracle.Model.interp(F, b, qs, ms_)
+    else:
+        g = api.Model.scattered_file(pointsfile)
+        o = oracle.Model.scattered_file(pointsfile, perm_seed=2 | 0x80000000)
+    g.set_field(use_igrf=1)
+    o.set_igrf(2010001, 0)
+    pos, d, w = wl.launch_set(192, 11)
+    pos = pos * 0.9
+    kw = dict(fixedstep=0, dt0=1e-3, dtmax=0.1, tmax=0.03, maxerr=5e-4, maxsteps=24, del_=1e-6)
+    rows, nrows, stop, steps = g.trace(pos, d, w, outputper=1, **kw)
+    orows, onrows, ostop, osteps = o.trace(pos, d, w, capacity=24, **kw)
+    both = (nrows > 4) & (onrows > 4)
+    assert both.sum() >= 80
+    B_err = np.linalg.norm(rows[both, 0, 13:16] - orows[both, 0, 13:16], axis=1) / np.linalg.norm(orows[both, 0, 13:16], axis=1)
+    assert B_err.max() <= 2e-6
+    assert np.array_equal(rows[both, 0, 1:4], orows[both, 0, 1:4])
+    same_t = np.all(rows[both, 1:4, 0] == orows[both, 1:4, 0], axis=1)
+    assert same_t.mean() >= 0.7, "time stamps of rows 1-3 agree on only %.0f %% of the rays" % (100 * same_t.mean())
+    assert np.mean(stop == ostop) >= 0.9
+    assert abs(int(steps) - int(osteps)) <= 0.1 * osteps
+    rows2, nrows2, stop2, _ = g.trace(pos, d, w, outputper=1, **kw)
+    assert np.array_equal(nrows, nrows2) and np.array_equal(stop, stop2) and np.array_equal(np.nan_to_num(rows), np.nan_to_num(rows2))
+    # the field option is per model: back to the dipole
+    g.set_field(use_igrf=0)
+    r3, _, _, _ = g.trace(pos[:8], d[:8], w[:8], outputper=1, **kw)
+    assert np.abs(r3[:, 0, 13:16] - rows[:8, 0, 13:16]).max() > 0

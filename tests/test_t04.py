@@ -127,3 +127,34 @@ def test_gpu_trace_with_t04_runs_and_differs_from_dipole(cfgfiles):
     assert 0 < rel.max() < 1e-2
     dB = np.linalg.norm(rt[both, 0, 13:16] - rd[both, 0, 13:16], axis=1) / np.linalg.norm(rd[both, 0, 13:16], axis=1)
     assert dB.max() > 1e-5 and np.median(dB) < 0.2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["interp", "scattered"])
+def test_gpu_t04_with_the_table_models(gold, grid16, pointsfile, name):
+    """use_tsyganenko = 1 with modelnum 3 and 4: the general field tail inside the trace kernels of the table models.
+    There is no T04 in the CPU oracle (it would be srt_t04.hpp a second time); what can be held: every row's field equals
+    funcPlasmaParams' field at the row's position (the layered kernel, itself held to the reference's goldens above), fixed
+    steps give identical row counts with and without the external field where it is negligible, run-to-run bit identity."""
+    from stanford_raytracer_amd import api
+    api.init(0)
+    F, b, qs, ms_ = grid16
+    g = api.Model.interp(F, b, qs, ms_) if name == "interp" else api.Model.scattered_file(pointsfile)
+    g.set_field(use_tsyganenko=1, parmod=gold["parmod"])
+    pos, d, w = wl.launch_set(96, 23)
+    pos = pos * 0.9
+    kw = dict(fixedstep=1, dt0=1e-3, dtmax=0.1, tmax=0.008, maxerr=5e-4, maxsteps=10, del_=1e-6)
+    rows, nrows, stop, steps = g.trace(pos, d, w, outputper=1, **kw)
+    assert set(np.unique(stop).tolist()) <= {0, 1, 2, 3, 5, 6, 9} and np.mean(stop == 9) < 0.05
+    live = nrows > 3
+    assert live.sum() >= 40
+    for r in (0, 1, 3):
+        want = g.plasma_params(rows[live, r, 1:4])[:, 16:19]
+        assert np.array_equal(rows[live, r, 13:16], want), r       # same device functions, same arguments
+    rows2, nrows2, stop2, _ = g.trace(pos, d, w, outputper=1, **kw)
+    assert np.array_equal(nrows, nrows2) and np.array_equal(np.nan_to_num(rows), np.nan_to_num(rows2))
+    g.set_field(use_tsyganenko=0)
+    rd, nd, _, _ = g.trace(pos, d, w, outputper=1, **kw)
+    dB = np.linalg.norm(rows[live, 0, 13:16] - rd[live, 0, 13:16], axis=1) / np.linalg.norm(rd[live, 0, 13:16], axis=1)
+    assert dB.max() > 1e-6 and np.median(dB) < 0.2
+    assert np.mean(nd == nrows) >= 0.9
