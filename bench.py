@@ -166,10 +166,17 @@ def child_args_for(args, workload, rays=0):
     return a
 
 
+def progress(msg):
+    if os.environ.get("RANK", "0") == "0":
+        sys.stderr.write("bench.py: %s\n" % msg)
+        sys.stderr.flush()
+
+
 def live_traffic(args, workload, rays=0):
     """FETCH_SIZE and WRITE_SIZE in SEPARATE passes (they do not fit one pass on gfx950) with the corrections of
     MI355X_MICROARCH.md (HBM section): both are KiB; FETCH_SIZE tallies 128-B requests at 64 B -> x2; WRITE_SIZE as read."""
     ca = child_args_for(args, workload, rays)
+    progress("counter passes (rocprofv3 --pmc FETCH_SIZE, then WRITE_SIZE) over one launch of %s" % workload)
     f, err = pmc_pass(["FETCH_SIZE"], ca)
     if f is None:
         return None, err
@@ -418,6 +425,7 @@ def main():
     api.init(local_rank)
     ctx = Ctx(args, torch, dev, dist, rank, world)
 
+    progress("%s: %d warm-up + %d timed steps on %d GPU(s)" % (args.workload, args.warmup, args.steps, world))
     res = run_workload(ctx, args.workload, args.steps, args.warmup, rays_override=args.rays, nstream=args.streams, keep=True)
     if args.pmc_child:  # the parent (pmc_pass) reads this line from the child's stdout
         print(json.dumps({"pmc_child": {"accepted": res["accepted"], "kernel_ms": res["kernel_ms_rank0"], "rays": res["rays_this_rank"]}}))
@@ -432,6 +440,7 @@ def main():
     if want_other:
         if world == 1:
             for name, st, wu in (("ngo100k", 3, 1), ("scattered825k", 1, 0), ("interp4m", 1, 1)):
+                progress("other config %s" % name)
                 other[name] = other_config_line(ctx, run_workload(ctx, name, st, wu), other_pmc.get(name))
         else:
             other["interp4m"] = other_config_line(ctx, run_workload(ctx, "interp4m", 2, 1), None)
@@ -493,6 +502,7 @@ def main():
             b = res["batch"]
             out["detail"]["damping"] = damping_leg(args, api, res["model"], p, b.slots, b.out[0]["rows"], b.out[0]["nrows"], b.d_w, dev, torch, res["nrows"])
         if args.cpu_seconds > 0 and world == 1:
+            progress("CPU baselines (oracle on the host cores, then the reference harness)")
             pos0, dir0, w0 = res["launch"]
             out["cpu_baseline"] = cpu_baseline(args, kind, p, wl, pos0, dir0, w0, res["grid"], res["extra"])
             # the real reference (Fortran, one core -- its only mode), when its prebuilt harness travelled with the repo
