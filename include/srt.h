@@ -173,10 +173,16 @@ int32_t srt_rows_per_ray(const srt_params *p);
  *   rows     [nrays][slots][SRT_ROW]   kept rows (row index r*outputper is stored in slot r)
  *   nrows    [nrays]                   total rows T the ray produced (= accepted steps + 1)
  *   stopcond [nrays]
- * accepted_steps (optional) receives sum(nrows-1). */
+ * accepted_steps (optional) receives sum(nrows-1).
+ * One call per model at a time: the device staging of this entry point is owned by the model handle and reused from call
+ * to call (grow-only; srt_model_trim() gives it back).  A second host thread calling it on the SAME model waits for the
+ * first (per-model lock); different models run concurrently. */
 int srt_trace_batch(srt_model *m, const srt_params *p, int64_t nrays, const double *pos0,
                     const double *dir0, const double *w0, double *rows, int32_t *nrows,
                     int32_t *stopcond, int64_t *accepted_steps);
+/* Frees the grow-only device scratch a model has accumulated (host-buffer staging of srt_trace_batch, per-launch sort and
+ * staging buffers); the tables stay.  The next call allocates what it needs again. */
+int srt_model_trim(srt_model *m);
 /* Same with every buffer already resident in device memory (what bench.py times).
  * d_pos0/d_dir0 are SoA on the device: [3][nrays].  stream = hipStream_t (NULL = default).
  * d_counters: 4 x int64 scratch/outputs: [0] queue head (zeroed by the call), [1] accepted steps,
@@ -190,7 +196,9 @@ int srt_trace_batch_device(srt_model *m, const srt_params *p, int64_t nrays, con
  * kept counts (d_offsets[nrays] = total), d_packed[total][SRT_ROW] the kept rows of ray 0, ray 1, ... back to back.
  * capacity_rows = rows d_packed can hold (nrays*slots always suffices; 0 = offsets only).  If the total exceeds the
  * capacity, the rays that do not fit are left out: compare d_offsets[nrays] with the capacity after synchronising.
- * All pointers are device memory; asynchronous on `stream`. */
+ * All pointers are device memory of ONE device -- the call finds that device from the buffers themselves (not from the
+ * calling thread's binding), works there and leaves the thread's device as it found it; buffers on different devices or
+ * host pointers fail with SRT_EINVAL.  `stream` must belong to the same device.  Asynchronous on `stream`. */
 int srt_pack_rows_device(int32_t slots, int32_t outputper, int64_t nrays, const double *d_rows,
                          const int32_t *d_nrows, int64_t *d_offsets, double *d_packed, int64_t capacity_rows,
                          void *stream);

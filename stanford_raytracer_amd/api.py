@@ -83,6 +83,7 @@ def lib():
     L.srt_model_set_tsyganenko_params.argtypes = [vp, dp]
     L.srt_model_destroy.argtypes = [vp]
     L.srt_model_destroy.restype = None
+    L.srt_model_trim.argtypes = [vp]
     L.srt_model_kind.argtypes = [vp]
     L.srt_model_nspec.argtypes = [vp]
     L.srt_model_species.argtypes = [vp, dp, dp]
@@ -252,6 +253,11 @@ class Model:
             _check(lib().srt_model_set_tsyganenko_params(self.h, _dp(_f64(parmod, (10,)))))
         _check(lib().srt_model_set_field(self.h, int(use_igrf), int(use_tsyganenko),
                                          os.fsencode(igrf_coeff_file) if igrf_coeff_file else None))
+        return self
+
+    def trim(self):
+        """Give back the grow-only device scratch (host-buffer staging, per-launch buffers); the tables stay."""
+        _check(lib().srt_model_trim(self.h))
         return self
 
     def close(self):

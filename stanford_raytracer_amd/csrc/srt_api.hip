@@ -48,6 +48,7 @@ extern "C" const char *srt_last_error(void) { return g_err.c_str(); }
 // --devices=0,1,..).  A model remembers the device it was created on, and every entry point that takes a model
 // switches to that device first, whichever thread calls it.
 #include <atomic>
+#include <mutex>
 static std::atomic<int> g_default_device{-1};
 static thread_local int t_device = -1;
 extern "C" int srt_init(int device) {
@@ -67,7 +68,32 @@ static int ensure_init() {
   t_device = dev;
   return SRT_OK;
 }
-static int current_device() { return t_device >= 0 ? t_device : 0; }
+// the device the calling thread is bound to right now (srt_init's, or a DeviceScope's)
+static int current_device() {
+  int d = -1;
+  if (hipGetDevice(&d) != hipSuccess) {
+    (void)hipGetLastError();
+    d = t_device >= 0 ? t_device : 0;
+  }
+  return d;
+}
+// An entry point that works on a model (or on buffers that live on some device) binds the calling thread to THAT device
+// for its own duration only: the thread's srt_init() binding (t_device) and whatever device the caller's own HIP / torch
+// code had selected are back in place when the call returns.
+struct DeviceScope {
+  int prev = -1;
+  int enter(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) {
+      prev = -1;
+      (void)hipGetLastError();
+    }
+    if (hipSetDevice(dev) != hipSuccess) return srt_set_error(SRT_EDEVICE, "hipSetDevice(%d) failed", dev);
+    return SRT_OK;
+  }
+  ~DeviceScope() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
 extern "C" int srt_device_info(char *name, int name_len, int *cu_count, int64_t *hbm_bytes) {
   int rc = ensure_init();
   if (rc) return rc;
@@ -108,6 +134,9 @@ struct srt_model {
     // scattered model (grow-only): staging records of coop_stencil, REC_CAP * REC doubles per one-wave block
     double *d_stage = nullptr;
     long long stage_blocks = 0;
+    // scattered model (grow-only): the lanes' candidate blocks, BLOCK_DOUBLES per one-wave block
+    double *d_blocks = nullptr;
+    long long cand_blocks = 0;
   };
   static constexpr int NSLOT = 4;
   LaunchSlot slot[NSLOT];
@@ -118,6 +147,7 @@ struct srt_model {
     void *p[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t cap[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   } io;
+  std::mutex io_lock; // one srt_trace_batch (host-buffer call) per model at a time: the staging above is shared
 };
 static int io_reserve(srt_model *m, int k, size_t bytes, void **out) {
   if (bytes > m->io.cap[k]) {
@@ -134,12 +164,9 @@ static int io_reserve(srt_model *m, int k, size_t bytes, void **out) {
   return SRT_OK;
 }
 
-// switch the calling thread to the model's device
-static int ensure_model(const srt_model *m) {
-  if (hipSetDevice(m->device) != hipSuccess) return srt_set_error(SRT_EDEVICE, "hipSetDevice(%d) failed", m->device);
-  t_device = m->device;
-  return SRT_OK;
-}
+// switch the calling thread to the model's device until the enclosing entry point returns
+#define ensure_model(m) (srt_dscope_.enter((m)->device))
+#define SRT_MODEL_SCOPE DeviceScope srt_dscope_
 
 static void fill_common(Common &cm, int nspec, const double *qs, const double *ms, int yearday, int msec) {
   memset(&cm, 0, sizeof cm);
@@ -191,7 +218,8 @@ static int model_finish(srt_model *m) {
 
 extern "C" void srt_model_destroy(srt_model *m) {
   if (!m) return;
-  (void)hipSetDevice(m->device); // its tables and events live there (the next entry point re-selects the caller's device)
+  SRT_MODEL_SCOPE; // its tables and events live on m->device; the caller's device is back when this returns
+  (void)ensure_model(m);
   if (m->d_coef) (void)hipFree(m->d_coef);
   if (m->d_pts) (void)hipFree(m->d_pts);
   if (m->d_xyz) (void)hipFree(m->d_xyz);
@@ -204,6 +232,7 @@ extern "C" void srt_model_destroy(srt_model *m) {
     }
     if (sl.d_sorttmp) (void)hipFree(sl.d_sorttmp);
     if (sl.d_stage) (void)hipFree(sl.d_stage);
+    if (sl.d_blocks) (void)hipFree(sl.d_blocks);
     if (sl.ev0) (void)hipEventDestroy(sl.ev0);
     if (sl.ev1) (void)hipEventDestroy(sl.ev1);
   }
@@ -212,12 +241,43 @@ extern "C" void srt_model_destroy(srt_model *m) {
     if (q) (void)hipFree(q);
   delete m;
 }
+extern "C" int srt_model_trim(srt_model *m) {
+  if (!m) return srt_set_error(SRT_EINVAL, "null model");
+  SRT_MODEL_SCOPE;
+  int rc = ensure_model(m);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> hold(m->io_lock);
+  for (auto &sl : m->slot) {
+    if (sl.used) HIP_OK(hipEventSynchronize(sl.ev1)); // the launch that used this slot's scratch is over
+    for (int k = 0; k < 2; ++k) {
+      if (sl.d_keys[k]) (void)hipFree(sl.d_keys[k]);
+      if (sl.d_ids[k]) (void)hipFree(sl.d_ids[k]);
+      sl.d_keys[k] = nullptr;
+      sl.d_ids[k] = nullptr;
+    }
+    if (sl.d_sorttmp) (void)hipFree(sl.d_sorttmp);
+    if (sl.d_stage) (void)hipFree(sl.d_stage);
+    if (sl.d_blocks) (void)hipFree(sl.d_blocks);
+    sl.d_sorttmp = nullptr;
+    sl.d_stage = nullptr;
+    sl.d_blocks = nullptr;
+    sl.sort_cap = sl.sorttmp_bytes = 0;
+    sl.stage_blocks = sl.cand_blocks = 0;
+  }
+  for (int k = 0; k < 9; ++k) {
+    if (m->io.p[k]) (void)hipFree(m->io.p[k]);
+    m->io.p[k] = nullptr;
+    m->io.cap[k] = 0;
+  }
+  return SRT_OK;
+}
 // use_igrf (raytracer_driver.f95 --use_igrf; interp_dens_model_adapter.f95:236-241 and twins)
 #include <dlfcn.h>
 extern "C" int srt_model_set_field(srt_model *m, int use_igrf, int use_tsyganenko, const char *igrf_coeff_file) {
   if (!m) return srt_set_error(SRT_EINVAL, "null model");
   if (use_tsyganenko != 0 && use_tsyganenko != 1) return srt_set_error(SRT_EINVAL, "use_tsyganenko must be 0 or 1");
   if (use_igrf != 0 && use_igrf != 1) return srt_set_error(SRT_EINVAL, "use_igrf must be 0 or 1");
+  SRT_MODEL_SCOPE;
   int rc = ensure_model(m);
   if (rc) return rc;
   FieldConst &f = m->cm.fld;
@@ -252,6 +312,7 @@ extern "C" int srt_model_set_field(srt_model *m, int use_igrf, int use_tsyganenk
 // T04_s's PARMOD (driver flags --tsyganenko_Pdyn, _Dst, _ByIMF, _BzIMF, _W1 .. _W6; raytracer_driver.f95:292-341)
 extern "C" int srt_model_set_tsyganenko_params(srt_model *m, const double parmod[10]) {
   if (!m || !parmod) return srt_set_error(SRT_EINVAL, "null argument");
+  SRT_MODEL_SCOPE;
   int rc = ensure_model(m);
   if (rc) return rc;
   for (int i = 0; i < 10; ++i) m->cm.fld.parmod[i] = (float)parmod[i]; // real(parmod)
@@ -666,13 +727,15 @@ static int check_grid_request(srt_model *src, int nx, int ny, int nz, const doub
   if (nx < 2 || ny < 2 || nz < 2) return srt_set_error(SRT_EINVAL, "grid must have >= 2 nodes per axis");
   if ((size_t)(nx + 1) * (ny + 1) * (nz + 1) >= (size_t)1 << 31) return srt_set_error(SRT_EINVAL, "grid too large");
   if (!(bounds[1] > bounds[0]) || !(bounds[3] > bounds[2]) || !(bounds[5] > bounds[4])) return srt_set_error(SRT_EINVAL, "empty bounds");
-  return ensure_model(src);
+  return SRT_OK;
 }
 
 extern "C" int srt_build_grid(srt_model *src, int compder, int nx, int ny, int nz, const double bounds[6], double *F,
                               double *derivs) {
   int rc = check_grid_request(src, nx, ny, nz, bounds);
   if (rc) return rc;
+  SRT_MODEL_SCOPE;
+  if ((rc = ensure_model(src))) return rc;
   if (!F || (compder && !derivs)) return srt_set_error(SRT_EINVAL, "null output");
   const size_t n = (size_t)nx * ny * nz * src->nspec;
   double *d_arr[8];
@@ -697,6 +760,8 @@ extern "C" int srt_model_create_interp_from_model(srt_model *src, int compder, i
   int rc = check_grid_request(src, nx, ny, nz, bounds);
   if (rc) return rc;
   if (!out) return srt_set_error(SRT_EINVAL, "null argument");
+  SRT_MODEL_SCOPE; // the new model is built beside its source, on the source's device
+  if ((rc = ensure_model(src))) return rc;
   const size_t n = (size_t)nx * ny * nz * src->nspec;
   double *d_arr[8];
   rc = alloc_grid_arrays(n, d_arr);
@@ -731,7 +796,14 @@ extern "C" int srt_model_create_scattered_file(const char *ptsfile, int yearday,
   if (rc) return rc;
   srt_host::ScatteredHost h;
   std::string err;
-  if (!srt_host::build_scattered(ptsfile, window_scale, h, err)) return srt_set_error(SRT_EIO, "%s: %s", ptsfile, err.c_str());
+  // reach of the trace kernel's candidate blocks beyond the search radius (srt_scattered.hpp; SRT_SCATTERED_MARGIN overrides
+  // the default for experiments; results do not depend on it beyond the order of summation)
+  double bmargin = 0.125;
+  if (const char *e = getenv("SRT_SCATTERED_MARGIN")) {
+    const double v = atof(e);
+    if (v >= 0.01 && v <= 1.0) bmargin = v;
+  }
+  if (!srt_host::build_scattered(ptsfile, window_scale, h, err, 1.0 + bmargin)) return srt_set_error(SRT_EIO, "%s: %s", ptsfile, err.c_str());
   srt_model *m = new srt_model;
   m->kind = 4;
   m->nspec = h.nspec;
@@ -760,6 +832,7 @@ extern "C" int srt_model_create_scattered_file(const char *ptsfile, int yearday,
   s.inv_cell = h.inv_cell;
   s.radius = h.radius;
   s.lws = local_window_scale;
+  s.bmargin = bmargin;
   s.nspec = h.nspec;
   s.order = order;
   s.exact = exact;
@@ -796,6 +869,12 @@ static bool staging_enabled() {
   return !(e && e[0] == '0');
 }
 
+// SRT_SCATTERED_BLOCKS=0: no candidate blocks, i.e. every shared-path stencil of the trace kernel scans the cells (A/B, tests)
+static bool blocks_enabled() {
+  const char *e = getenv("SRT_SCATTERED_BLOCKS");
+  return !(e && e[0] == '0');
+}
+
 // scattered model: staging records for the one-wave blocks serving n items (srt_scattered.hpp shared_fit); beyond
 // 4096 blocks (2 GiB) the kernels run without (own-list path)
 static void stage_alloc(DevBuf &b, int64_t n) {
@@ -816,6 +895,7 @@ extern "C" int srt_plasma_params(srt_model *m, int64_t n, const double *x, doubl
                                  double *nus, double *B0) {
   if (!m || !x || n < 0) return srt_set_error(SRT_EINVAL, "bad argument");
   if (n == 0) return SRT_OK;
+  SRT_MODEL_SCOPE;
   int rc = ensure_model(m);
   if (rc) return rc;
   DevBuf dx, dout;
@@ -844,6 +924,7 @@ extern "C" int srt_plasma_params(srt_model *m, int64_t n, const double *x, doubl
 extern "C" int srt_dispersion(srt_model *m, int64_t n, const double *x, const double *k, const double *w, double *out) {
   if (!m || !x || !k || !w || !out || n < 0) return srt_set_error(SRT_EINVAL, "bad argument");
   if (n == 0) return SRT_OK;
+  SRT_MODEL_SCOPE;
   int rc = ensure_model(m);
   if (rc) return rc;
   DevBuf dx, dk, dw, dout;
@@ -879,6 +960,7 @@ extern "C" int srt_is_right_handed(int64_t n, const double *in, int32_t *out) {
 extern "C" int srt_gradients(srt_model *m, int64_t n, const double *x, const double *k, const double *w, double del, double *out) {
   if (!m || !x || !k || !w || !out || n < 0) return srt_set_error(SRT_EINVAL, "bad argument");
   if (n == 0) return SRT_OK;
+  SRT_MODEL_SCOPE;
   int rc = ensure_model(m);
   if (rc) return rc;
   DevBuf dx, dk, dw, dout;
@@ -902,6 +984,7 @@ extern "C" int srt_gradients(srt_model *m, int64_t n, const double *x, const dou
 extern "C" int srt_rk_step(srt_model *m, int64_t n, const double *args, const double *dt, double del, double *out) {
   if (!m || !args || !dt || !out || n < 0) return srt_set_error(SRT_EINVAL, "bad argument");
   if (n == 0) return SRT_OK;
+  SRT_MODEL_SCOPE;
   int rc = ensure_model(m);
   if (rc) return rc;
   DevBuf da, dd, dout;
@@ -966,6 +1049,7 @@ extern "C" int srt_build_samples(srt_model *src, const srt_sampler_params *sp, i
   if (sp->n_zero_altitude < 0 || sp->n_iri_pad < 0 || sp->n_initial_radial < 0 || sp->n_initial_uniform < 0 || sp->max_recursion < 0 ||
       sp->numincrease < 0)
     return srt_set_error(SRT_EINVAL, "negative count");
+  SRT_MODEL_SCOPE;
   int rc = ensure_model(src);
   if (rc) return rc;
   const int nspec = src->nspec, ninc = sp->numincrease ? sp->numincrease : 5;
@@ -1189,6 +1273,7 @@ extern "C" int srt_trace_batch_device(srt_model *m, const srt_params *p, int64_t
     return srt_set_error(SRT_EINVAL, "bad argument");
   int rc = check_params(p);
   if (rc) return rc;
+  SRT_MODEL_SCOPE;
   if ((rc = ensure_model(m))) return rc;
   hipStream_t st = (hipStream_t)stream;
   TraceArgs a;
@@ -1210,7 +1295,8 @@ extern "C" int srt_trace_batch_device(srt_model *m, const srt_params *p, int64_t
   a.order = nullptr;
   HIP_OK(hipMemsetAsync(d_counters, 0, 4 * sizeof(int64_t), st));
   // persistent grid: enough one-wave blocks to fill the chip, never more than the rays need
-  int per_cu = (m->kind == 3 || m->kind == 4) ? 4 : 8; // interp / scattered: 34 KiB of LDS per wave, 512 registers per lane
+  // interp: 34 KiB of LDS per wave, 512 registers per lane: one wave per SIMD; scattered: 18.5 KiB, <= 256 registers: two
+  int per_cu = m->kind == 3 ? 4 : (m->kind == 4 ? 4 * ScatteredModel::WAVES_PER_EU : 8);
   if (const char *e = getenv("SRT_WAVES_PER_CU")) {
     const int v = atoi(e);
     if (v >= 1 && v <= per_cu) per_cu = v;
@@ -1277,6 +1363,18 @@ extern "C" int srt_trace_batch_device(srt_model *m, const srt_params *p, int64_t
       else (void)hipGetLastError();
     }
     a.scratch = sl.d_stage;
+  }
+  a.scratch2 = nullptr;
+  if (m->kind == 4 && a.scratch != nullptr && blocks_enabled()) { // without them the kernel scans the cells for every stencil
+    if (grid > sl.cand_blocks) {
+      if (sl.used) HIP_OK(hipEventSynchronize(sl.ev1));
+      if (sl.d_blocks) (void)hipFree(sl.d_blocks);
+      sl.d_blocks = nullptr;
+      sl.cand_blocks = 0;
+      if (hipMalloc(&sl.d_blocks, (size_t)grid * ScatteredModel::BLOCK_DOUBLES * sizeof(double)) == hipSuccess) sl.cand_blocks = grid;
+      else (void)hipGetLastError();
+    }
+    a.scratch2 = sl.d_blocks;
   }
   const bool fixed = p->fixedstep != 0;
   const int fopt = m->cm.fld.use_tsy != 0 ? 2 : (m->cm.fld.use_igrf != 0 ? 1 : 0);
@@ -1469,7 +1567,25 @@ extern "C" int srt_pack_rows_device(int32_t slots, int32_t outputper, int64_t nr
   if (!d_offsets || nrays < 0 || slots < 1 || outputper < 1 || capacity_rows < 0 ||
       (nrays > 0 && (!d_rows || !d_nrows || (!d_packed && capacity_rows > 0))))
     return srt_set_error(SRT_EINVAL, "bad argument");
-  int rc = ensure_init();
+  // The work goes to the device that OWNS the buffers (not to whatever device the calling thread happens to be bound to):
+  // a process may drive several GPUs from one thread.  All buffers must live on one device.
+  int dev = -1;
+  {
+    const void *ptrs[4] = {d_offsets, nrays > 0 ? (const void *)d_rows : nullptr, nrays > 0 ? (const void *)d_nrows : nullptr,
+                           nrays > 0 && capacity_rows > 0 ? (const void *)d_packed : nullptr};
+    for (const void *q : ptrs) {
+      if (!q) continue;
+      hipPointerAttribute_t at;
+      if (hipPointerGetAttributes(&at, q) != hipSuccess || at.type != hipMemoryTypeDevice) {
+        (void)hipGetLastError();
+        return srt_set_error(SRT_EINVAL, "srt_pack_rows_device: %p is not device memory", q);
+      }
+      if (dev < 0) dev = at.device;
+      else if (at.device != dev) return srt_set_error(SRT_EINVAL, "srt_pack_rows_device: buffers live on devices %d and %d", dev, at.device);
+    }
+  }
+  DeviceScope scope;
+  int rc = scope.enter(dev);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   if (nrays == 0) {
@@ -1486,8 +1602,9 @@ extern "C" int srt_pack_rows_device(int32_t slots, int32_t outputper, int64_t nr
   void *tmp = nullptr;
   HIP_OK(hipMallocAsync(&tmp, need ? need : 16, st));
   hipError_t e = hipcub::DeviceScan::ExclusiveSum(tmp, need, counts, (long long *)d_offsets, (int)nrays, st);
-  if (e == hipSuccess) e = hipFreeAsync(tmp, st);
+  const hipError_t ef = hipFreeAsync(tmp, st); // (also on the error path)
   HIP_OK(e);
+  HIP_OK(ef);
   // offsets[nrays] = offsets[nrays-1] + kept(nrays-1)
   hipLaunchKernelGGL(pack_total_kernel, dim3(1), dim3(1), 0, st, KeptRows{d_nrows, outputper, slots}, (long long)nrays, (long long *)d_offsets);
   if (capacity_rows > 0) {
@@ -1520,7 +1637,9 @@ extern "C" int srt_trace_batch(srt_model *m, const srt_params *p, int64_t nrays,
     if (accepted_steps) *accepted_steps = 0;
     return SRT_OK;
   }
+  SRT_MODEL_SCOPE;
   if ((rc = ensure_model(m))) return rc;
+  std::lock_guard<std::mutex> hold(m->io_lock); // the staging below belongs to the model
   const int slots = srt_rows_per_ray(p);
   const size_t nrow_d = (size_t)nrays * slots * SRT_ROW;
   double *a_pos, *a_dir, *s_pos, *s_dir, *dw, *drows;

@@ -52,6 +52,7 @@ struct TraceArgs {
   int *stopcond;      // [nrays]
   unsigned long long *counters; // [0] queue head, [1] accepted steps, [2] attempts, [3] wave-attempts (loop trips of all waves)
   double *scratch;    // scattered model: staging records, ScatteredModel::REC_CAP * REC doubles per block (or nullptr)
+  double *scratch2;   // scattered model: candidate blocks, ScatteredModel::BLOCK_DOUBLES doubles per block (or nullptr)
   TraceParams p;
 };
 
@@ -254,14 +255,14 @@ __device__ __forceinline__ void store_row(double *row, double t, const double x[
 // FOPT: field option fixed at compile time -- 0 dipole, 1 IGRF main field alone, 2 the general tail (T04_s on an IGRF or
 // dipole base, chosen at run time inside)
 template <class M, bool FIXED, bool USE_LDS, int FOPT = 0>
-__global__ __launch_bounds__(64) void trace_kernel(const M *__restrict__ mp, const Common *__restrict__ cp, TraceArgs a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WaveBudget<M>::WAVES_PER_EU))) void trace_kernel(const M *__restrict__ mp, const Common *__restrict__ cp, TraceArgs a) {
   const M &m = *mp;
   constexpr bool IGRF = FOPT != 0;
   typedef typename std::conditional<FOPT == 0, CommonDipole, typename std::conditional<FOPT == 1, CommonIgrfOnly, CommonIgrf>::type>::type CM;
   const CM &cm = *static_cast<const CM *>(cp);
-  __shared__ __attribute__((aligned(16))) double tile[USE_LDS ? TILE_DOUBLES : 2];
+  __shared__ __attribute__((aligned(16))) double tile[USE_LDS ? WaveBudget<M>::LDS_DOUBLES : 2];
   double *lds = USE_LDS ? tile : nullptr;
-  bind_scratch(m, lds, a.scratch);
+  bind_scratch(m, lds, a.scratch, a.scratch2);
   const TraceParams &P = a.p;
   const int lane = threadIdx.x;
   const Tableau &tab = FIXED ? TAB_RK4 : TAB_RKF45;
@@ -317,6 +318,7 @@ __global__ __launch_bounds__(64) void trace_kernel(const M *__restrict__ mp, con
           if (a.order) id = a.order[id];
           ray = id;
           needinit = true;
+          new_ray_hook(m, lds, true);
           x[0] = a.pos0[id];
           x[1] = a.pos0[a.nrays + id];
           x[2] = a.pos0[2 * a.nrays + id];
@@ -642,12 +644,12 @@ __global__ void handedness_kernel(long long n, const double *in, int *out) {
 
 // out[n][14] = dFdk(3), dFdw, dFdx(3), rhs(7)
 template <class M, bool USE_LDS>
-__global__ __launch_bounds__(64) void gradients_kernel(const M *__restrict__ mp, const Common *__restrict__ cp, long long n, const double *x,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WaveBudget<M>::WAVES_PER_EU))) void gradients_kernel(const M *__restrict__ mp, const Common *__restrict__ cp, long long n, const double *x,
                                                        const double *k, const double *w, double del,
                                                        double *out, double *scratch) {
   const M &m = *mp;
   const Common &cm = *cp;
-  __shared__ __attribute__((aligned(16))) double tile[USE_LDS ? TILE_DOUBLES : 2];
+  __shared__ __attribute__((aligned(16))) double tile[USE_LDS ? WaveBudget<M>::LDS_DOUBLES : 2];
   bind_scratch(m, USE_LDS ? tile : nullptr, scratch);
   long long i = (long long)blockIdx.x * WAVE + threadIdx.x;
   long long j = i < n ? i : n - 1;
@@ -681,11 +683,11 @@ __global__ __launch_bounds__(64) void gradients_kernel(const M *__restrict__ mp,
 
 // out[n][21] = rk4(7), rk45 4th(7), rk45 5th(7)
 template <class M, bool USE_LDS>
-__global__ __launch_bounds__(64) void rkstep_kernel(const M *__restrict__ mp, const Common *__restrict__ cp, long long n, const double *args,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WaveBudget<M>::WAVES_PER_EU))) void rkstep_kernel(const M *__restrict__ mp, const Common *__restrict__ cp, long long n, const double *args,
                                                     const double *dtv, double del, double *out, double *scratch) {
   const M &m = *mp;
   const Common &cm = *cp;
-  __shared__ __attribute__((aligned(16))) double tile[USE_LDS ? TILE_DOUBLES : 2];
+  __shared__ __attribute__((aligned(16))) double tile[USE_LDS ? WaveBudget<M>::LDS_DOUBLES : 2];
   bind_scratch(m, USE_LDS ? tile : nullptr, scratch);
   long long i = (long long)blockIdx.x * WAVE + threadIdx.x;
   long long j = i < n ? i : n - 1;

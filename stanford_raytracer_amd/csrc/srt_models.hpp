@@ -32,7 +32,17 @@ __device__ __forceinline__ unsigned long long *srt_tt_lds() {
 
 // Per-launch device scratch of a model (only the scattered model has any: srt_scattered.hpp overloads this).
 template <class M>
-__device__ __forceinline__ void bind_scratch(const M &, double *, double *) {}
+__device__ __forceinline__ void bind_scratch(const M &, double *, double *, double * = nullptr) {}
+// A lane of the trace kernel has just been given a new ray (the scattered model forgets the lane's candidate block).
+template <class M>
+__device__ __forceinline__ void new_ray_hook(const M &, double *, bool) {}
+// What the cooperative kernels (trace, gradients, RK step) reserve per wave for a model: LDS (in doubles) and the waves per
+// SIMD the kernel is compiled for (1: all 512 registers of a lane; the scattered model specialises this: srt_scattered.hpp).
+template <class M>
+struct WaveBudget {
+  static constexpr int LDS_DOUBLES = TILE_DOUBLES;
+  static constexpr int WAVES_PER_EU = 1;
+};
 #define SRT_AS1 __attribute__((address_space(1)))
 #define SRT_AS3 __attribute__((address_space(3)))
 

@@ -18,6 +18,7 @@
 namespace srt {
 
 #define SRT_LDS __attribute__((address_space(3)))
+typedef float f4_t __attribute__((ext_vector_type(4)));
 
 // Build with -DSRT_PHASE_TIMING for a cycle breakdown of coop_stencil (srt_phase_cycles[], printed after every trace
 // launch when the environment variable SRT_PHASE_TIMING is set): 0 scan, 1 pass 1, 2 its reductions, 3 base pass,
@@ -26,7 +27,7 @@ namespace srt {
 __device__ unsigned long long srt_phase_cycles[16];
 // per-wave counters in LDS (behind the lists, the staging pointer and the hand-off area), flushed to the global ones
 // once per coop_stencil call: an atomic per phase and stencil would itself show up in whatever waits on memory next
-#define SRT_PHASE_LDS ((SRT_LDS unsigned long long *)srt_lds_base_ + (32768 + 512) / 8)
+#define SRT_PHASE_LDS ((SRT_LDS unsigned long long *)srt_lds_base_ + ScatteredModel::LDS_PHASE)
 #define SRT_PHASE_BEGIN(ldsbase)                                                                     \
   SRT_LDS char *srt_lds_base_ = (SRT_LDS char *)(ldsbase);                                           \
   unsigned long long srt_t0_ = __builtin_readcyclecounter()
@@ -150,6 +151,11 @@ struct MomentsT {
     mono[0] = 1.0;
     ((mono[I + 1] = mono[C<I + 1>::par] * d[C<I + 1>::ax]), ...);
   }
+  // the same chain with mono[0] given (a weight: every entry then carries it)
+  template <int NM, int... I>
+  __device__ __forceinline__ static void monomials_from(double (&mono)[NM], const double (&d)[3], std::integer_sequence<int, I...>) {
+    ((mono[I + 1] = mono[C<I + 1>::par] * d[C<I + 1>::ax]), ...);
+  }
   template <int... T>
   __device__ __forceinline__ static void expand(const double (&M)[N], double (&A)[NT], std::integer_sequence<int, T...>) {
     ((A[T] = M[P<T>::mom]), ...);
@@ -165,11 +171,82 @@ static_assert(Moments::of_m(4) == mom::find(0, 1, 1) && Moments::of_m(9) == mom:
                   MomentsT<3>::of_m(12) == mom::find(1, 0, 2),
               "tabular_monomials order");
 
+// Elementary functions on the argument ranges of the shared path's per-sample passes (pass 1 / base pass of shared_fit: no
+// accumulators are alive there, so instruction count is what they cost).  Each is the textbook (fdlibm) kernel without the
+// library's range handling -- arguments here are never denormal, huge, negative or NaN-by-construction -- and agrees with
+// the library to <= 1-2 ulp; the weights they feed are common to the seven stencil points of a fit.
+namespace fm {
+// sqrt for 0 <= x, neither denormal nor near overflow: the compiler's own sequence (v_rsq_f64, one Goldschmidt step, two
+// residual corrections) without its range scaling
+__device__ __forceinline__ double sqrt_pos(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  const double r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  double d = fma(-g, g, x);
+  g = fma(d, h, g);
+  d = fma(-g, g, x);
+  g = fma(d, h, g);
+  return x == 0.0 ? 0.0 : g;
+}
+// sin and cos of a in [0, pi (1 + 2e-3)]: quadrant k = 0, 1, 2, t = a - k pi/2 in about [-pi/4, pi/4]
+__device__ __forceinline__ void sincos_0pi(double a, double &s, double &c) {
+  const double PIO2_HI = 1.57079632673412561417e+00, PIO2_LO = 6.07710050650619224932e-11; // k * hi is exact (33 bits)
+  const double kf = a > 0.75 * PI ? 2.0 : (a > 0.25 * PI ? 1.0 : 0.0);
+  const double t = fma(-kf, PIO2_LO, fma(-kf, PIO2_HI, a));
+  const double z = t * t;
+  const double rs = 8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 + z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
+  const double st = t + (z * t) * (-1.66666666666666324348e-01 + z * rs);
+  const double rc = z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 + z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
+  const double hz = 0.5 * z, w = 1.0 - hz;
+  const double ct = w + (((1.0 - w) - hz) + z * rc);
+  s = kf == 1.0 ? ct : (kf == 2.0 ? -st : st);
+  c = kf == 1.0 ? -st : (kf == 2.0 ? -ct : ct);
+}
+// ln x for a positive normal x
+__device__ __forceinline__ double log_pos(double x) {
+  double m = __builtin_amdgcn_frexp_mant(x); // [0.5, 1)
+  int e = __builtin_amdgcn_frexp_exp(x);
+  const bool low = m < 0.70710678118654752440;
+  m = low ? m + m : m; // [sqrt(1/2), sqrt 2)
+  e = low ? e - 1 : e;
+  const double f = m - 1.0, k = (double)e;
+  const double sq = fdiv(f, 2.0 + f), z = sq * sq, w = z * z;
+  const double t1 = w * (3.999999999940941908e-01 + w * (2.222219843214978396e-01 + w * 1.531383769920937332e-01));
+  const double t2 = z * (6.666666666666735130e-01 + w * (2.857142874366239149e-01 + w * (1.818357216161805012e-01 + w * 1.479819860511658591e-01)));
+  const double R = t2 + t1, hfsq = 0.5 * f * f;
+  return k * 6.93147180369123816490e-01 - ((hfsq - (sq * (hfsq + R) + k * 1.90821492927058770002e-10)) - f);
+}
+// e^y for y <= ~700 (underflows to 0 below -745)
+__device__ __forceinline__ double exp_any(double y) {
+  y = fmax(y, -800.0);
+  const double k = rint(y * 1.44269504088896338700e+00);
+  const double r = fma(-k, 1.90821492927058770002e-10, fma(-k, 6.93147180369123816490e-01, y)); // |r| <= 0.3466
+  double p = 1.0 / 6227020800.0;
+  p = fma(p, r, 1.0 / 479001600.0);
+  p = fma(p, r, 1.0 / 39916800.0);
+  p = fma(p, r, 1.0 / 3628800.0);
+  p = fma(p, r, 1.0 / 362880.0);
+  p = fma(p, r, 1.0 / 40320.0);
+  p = fma(p, r, 1.0 / 5040.0);
+  p = fma(p, r, 1.0 / 720.0);
+  p = fma(p, r, 1.0 / 120.0);
+  p = fma(p, r, 1.0 / 24.0);
+  p = fma(p, r, 1.0 / 6.0);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return ldexp(p, (int)k);
+}
+} // namespace fm
+
 struct ScatteredModel {
   const double *pts;     // [npts][8]: x, y, z, lnN[4], nearest-sample distance
   const double *xyz;     // [3][npts]: the positions once more, SoA (candidate scans: 24 coalesced bytes per sample, not 64)
   const int *cell_start; // [ncells + 1]
   double origin[3], inv_cell, radius, lws;
+  double bmargin; // candidate blocks (coop_stencil) hold the samples within radius * (1 + bmargin) of their centre; the grid's cell edge is that too
   int dims[3];
   int nspec, order, exact, npts;
 
@@ -200,6 +277,7 @@ struct ScatteredModel {
     M.inv_cell = uni(self->inv_cell);
     M.radius = uni(self->radius);
     M.lws = uni(self->lws);
+    M.bmargin = uni(self->bmargin);
     M.nspec = uni(self->nspec);
     M.order = uni(self->order);
     M.exact = uni(self->exact);
@@ -513,7 +591,24 @@ struct ScatteredModel {
   // per-neighbour work (weights, the 55 + 40 normal-equation terms), 8 lanes splitting the samples.  The partial sums
   // of the 8 lanes are combined by DPP within the group.  Per point the terms are those of interpolate<J>; only the
   // order of summation differs (it is RNG-dependent in the reference anyway, SURVEY A-12).
-  static constexpr int LIST_CAP = 1024; // entries per group: 8 groups x 4 KiB = 32 KiB of the wave's LDS
+  // LDS of a wave, in doubles (L = LIST_DOUBLES):
+  //   [0, L)  the list area -- one shared candidate list of SHARED_CAP entries, or 8 own lists of LIST_CAP, or (pass 2) the
+  //           ring of NBUF 64-record buffers;   L staging-buffer pointer;  L + 1 candidate-block pointer;
+  //   [L + 2, L + 34) the groups' results on their way to the owner;  [L + 34, L + 50) cycle counters (timing builds);
+  //   [L + 64, L + 320) the 64 lanes' candidate-block headers {centre x, y, z, entry count (int; -1 = none)}
+#ifndef SRT_SCAT_WAVES
+#define SRT_SCAT_WAVES 2 // waves per SIMD the cooperative kernels of this model are built for (1: 34.5 KiB of LDS, 512 registers)
+#endif
+  static constexpr int WAVES_PER_EU = SRT_SCAT_WAVES;
+  static constexpr int NBUF = WAVES_PER_EU == 2 ? 2 : 4;  // 64-record buffers of pass 2's ring
+  static constexpr int LIST_DOUBLES = NBUF * 1024;          // the list area: NBUF x 8 KiB
+  static constexpr int LIST_CAP = LIST_DOUBLES / 4;         // entries per group (8 groups x 4 bytes)
+  static constexpr int LDS_SCRATCH_SLOT = LIST_DOUBLES, LDS_BLOCK_SLOT = LDS_SCRATCH_SLOT + 1, LDS_PARK = LDS_SCRATCH_SLOT + 2,
+                       LDS_PHASE = LDS_PARK + 32, LDS_HDR = LDS_SCRATCH_SLOT + 64;
+  static constexpr int LDS_DOUBLES = LDS_HDR + 4 * 64;
+  // candidate block of a lane: BLOCK_CAP entries {float dx, dy, dz (from the block's centre), int sample index}
+  static constexpr int BLOCK_CAP = 4096, BLOCK_DOUBLES = 64 * BLOCK_CAP * 2;
+  static constexpr int TRIP_MAX = 9 * 64; // entries one trip of a 27-cell scan can add
 
   template <int CTRL>
   __device__ __forceinline__ static double dpp_move(double v) {
@@ -590,9 +685,9 @@ struct ScatteredModel {
     return flushed;
   }
 
+  // dposv 'U' on the packed upper triangle (row a holds A[a][a..J-1]) with right-hand side e_1: A = U^T U, U^T z = e_1, U y = z
   template <int J>
-  __device__ __forceinline__ static int solve_fit(double (&A)[J * (J + 1) / 2], const double (&b)[J][4], double fi[4]) {
-    // dposv 'U': A = U^T U, packed upper triangle, row a holds A[a][a..J-1]
+  __device__ __forceinline__ static int chol_y(double (&A)[J * (J + 1) / 2], double (&y)[J]) {
     auto at = [&](int r, int c) -> double & { return A[r * J - r * (r - 1) / 2 + (c - r)]; };
 #pragma unroll
     for (int j = 0; j < J; ++j) {
@@ -610,7 +705,6 @@ struct ScatteredModel {
         at(j, c) = t * inv;
       }
     }
-    double y[J];
 #pragma unroll
     for (int i = 0; i < J; ++i) { // U^T z = e_1
       double t = (i == 0) ? 1.0 : 0.0;
@@ -625,11 +719,37 @@ struct ScatteredModel {
       for (int l = i + 1; l < J; ++l) t -= at(i, l) * y[l];
       y[i] = t / at(i, i);
     }
+    return 0;
+  }
+  template <int J>
+  __device__ __forceinline__ static int solve_fit(double (&A)[J * (J + 1) / 2], const double (&b)[J][4], double fi[4]) {
+    double y[J];
+    if (chol_y<J>(A, y) != 0) return 1;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       double acc = 0.0;
 #pragma unroll
       for (int j = 0; j < J; ++j) acc += y[j] * b[j][s];
+      fi[s] = acc;
+    }
+    return 0;
+  }
+  // Order 2 on the shared path: the group's 75 totals are parked in LDS (area[0..34] the moments, area[35 + 4 a + s] the
+  // right-hand sums) so that no accumulator is alive during the factorisation -- at two waves per SIMD (256 registers) the
+  // solve otherwise runs out of scratch memory, one dependent reload after the other.
+  template <int... T>
+  __device__ __forceinline__ static void expand_parked(SRT_LDS const double *area, double (&A)[55], std::integer_sequence<int, T...>) {
+    ((A[T] = area[Moments::P<T>::mom]), ...);
+  }
+  __device__ __forceinline__ static int solve10_parked(SRT_LDS const double *area, double fi[4]) {
+    double A[55], y[10];
+    expand_parked(area, A, std::make_integer_sequence<int, 55>{});
+    if (chol_y<10>(A, y) != 0) return 1;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      double acc = 0.0;
+#pragma unroll
+      for (int j = 0; j < 10; ++j) acc += y[j] * area[35 + 4 * j + s];
       fi[s] = acc;
     }
     return 0;
@@ -650,348 +770,387 @@ struct ScatteredModel {
   };
   static constexpr int SHARED_CAP = 8 * LIST_CAP;
   // ---- the shared-list path: staged neighbour records ------------------------------------------------------------
-  // The stencil points 1..6 sit within ~1e-6 |x| of the centre, so for one sample the arguments of the weight's
-  // transcendental functions (cos of the window, x**1.1 and exp of etainv) differ between those points by ~1e-6
-  // relative.  They are therefore evaluated ONCE per sample, at the centre, by a lane that owns the sample (64 samples
-  // per trip, no accumulators alive), and parked with the sample in a per-wave staging buffer in device memory
-  // (REC doubles per sample).  Pass 2 then gets the weight at its own point from the centre's values by short series in
-  // the differences -- with dr = r_g - r_c, tau = (1 + dr/(r_c + R eps)) (h_c/h_g) - 1:
-  //     x_g**1.1 = u_c (1 + tau)**1.1            binomial series to tau^5        (|tau| <= 1e-3: remainder 3e-21)
-  //     exp(-u_g) = E_c exp(-du), du = u_g - u_c  exponential series to du^6      (|du|  <= 1.2e-3: remainder 7e-25)
-  //     cos(a_c + da) = ca cos da - sa sin da     da = pi dr / R <= 3.2e-3, series to da^4 / da^5 (remainder 1e-18)
-  // i.e. the same numbers as etainv() to within its own rounding (both carry ~u_c * 2^-53 from the rounding of r).
-  // Samples for which the bounds do not hold (a sample within ~1e3 stencil widths of the centre; exact == 1; no usable
-  // centre) are "direct": the owning lane evaluates etainv() itself for the points 0..6 and parks the seven weights.
-  // The free point 7 (the other end-point estimate of the step, up to maxerr |x| away) is always direct.
-  // Record: [0..2] x y z, [3..6] ln N_s, [7] 0 = series / 1 = direct, series: [8] r_c [9] 1/(r_c + R eps) [10] cos a_c
-  // [11] sin a_c [12] u_c [13] E_c; direct: [8 + g] weight at point g; [15] weight at point 7.
+  // The stencil points 1..6 sit within ~1e-6 |x| of the centre (and the free point 7, the other end-point estimate of
+  // the same step, within some tens of metres), so for one sample the arguments of the weight's transcendental functions
+  // (cos of the window, x**1.1 and exp of etainv) differ between the eight points by ~1e-6 relative.  The path has three
+  // phases, each its own out-of-line function (its own register allocation: at two waves per SIMD there are 256):
+  //
+  //  sf_pass1    lane = sample (64 per trip): the sample is gathered, r_c, cos a_c, sin a_c at the centre are evaluated
+  //              once, the cosine windows of the other points follow by the addition theorem from
+  //              dr = r_g - r_c (|pi dr / R| <= 3.2e-3, series to da^4 / da^5: remainder 1e-18), and the eight
+  //              window-weighted mean spacings h_g (lsinterp_mod.f95:296-303) are reduced over the wave.  The sample goes
+  //              to a per-wave staging buffer in device memory (REC doubles per sample) with r_c, cos, sin.
+  //  sf_weights  lane = sample again, now with the h_g known: ALL EIGHT weights of the sample, sharing what they can --
+  //              with t_g = r_g^2 - r_c^2 = delta (delta -+ 2 d_a) taken from the offsets directly (no cancellation, no
+  //              square root), eps = t_g / r_c^2, dr = (t_g / 2 r_c)(1 - eps/4 + eps^2/8 - 5 eps^3/64 + 7 eps^4/128)
+  //              (|eps| <= 2e-3: remainder 1e-15 dr), tau = (1 + dr/(r_c + R eps0)) (h_c/h_g) - 1:
+  //                  x_g**1.1 = u_c (1 + tau)**1.1            binomial series to tau^5     (|tau| <= 1e-3: remainder 3e-21)
+  //                  exp(-u_g) = E_c exp(-du), du = u_g - u_c  exponential series to du^6   (|du| <= 1.2e-3: remainder 7e-25)
+  //                  cos(a_c + da) = ca cos da - sa sin da
+  //              i.e. the same numbers as etainv() to within its own rounding (both carry ~u_c * 2^-53 from the rounding
+  //              of r).  u_c = a sh with a = (r_c + R eps0)**1.1 and sh = (h_c / 4)**-1.1.  Samples for which the bounds
+  //              do not hold (within ~1e3 stencil widths of the centre; exact == 1; no usable centre) are "direct": their
+  //              weights come from etainv() itself.  The eight half-weights 0.5 eta (0 = not a neighbour of that point,
+  //              or masked, :316-317) replace r_c, cos, sin .. in the record.
+  //  sf_sums     lane = (point g, 1 of 8): group g walks the records -- through a ring of 64-record buffers in LDS filled by
+  //              LDS-DMA -- and accumulates the normal equations of its point from {x, y, z, ln N_s, weight g}: no
+  //              transcendental function, no series and no branch in the loop.
+  // Record: [0..2] x y z, [3..6] ln N_s, [7] -, after pass 1: [8] r_c [10] cos a_c [11] sin a_c; after the weights:
+  // [8 + g] half-weight at point g (g < 7), [15] at the free point.
   static constexpr int REC = 16, REC_CAP = 4096;
-  static constexpr int LDS_SCRATCH_SLOT = SHARED_CAP / 2; // (in doubles) the wave's staging-buffer pointer sits behind the lists
 
   __device__ __forceinline__ double etainv_at(double ss, double hin) const { return etainv(sqrt(ss), hin); }
 
-  template <int J>
-  __device__ __noinline__ Fit4 shared_fit(const double (&p_in)[3], bool live, unsigned long long livemask, int npts, int n_list,
-                                          SRT_LDS const int *list, double *rec_flat, double dmax) const {
-    Fit4 fi;
+  // what pass 1 hands on through LDS (the park area is free until the hand-off at the end of the stencil)
+  struct Pass1Out {
+    double hin8[8];
+    int cnt8[8];
+  };
+  __device__ __forceinline__ static SRT_LDS Pass1Out *pass1_out(SRT_LDS const int *list) {
+    return (SRT_LDS Pass1Out *)((SRT_LDS double *)const_cast<SRT_LDS int *>(list) + LDS_PARK);
+  }
+  static_assert(sizeof(Pass1Out) <= 32 * 8, "Pass1Out must fit the park area");
+
+  // p7near: the free point 7 lies as close to the centre as the six offset points may (<= 1e-3 radius) and takes the
+  // addition theorem / the series like them; else its window is evaluated by cos() and its weight by etainv().
+  __device__ __noinline__ void sf_pass1(const double (&p_in)[3], unsigned long long livemask, int npts, int n_list,
+                                        SRT_LDS const int *list, double *rec_flat, bool p7near) const {
     const ScatteredModel M = uniform_copy();
-    const double p[3] = {p_in[0], p_in[1], p_in[2]}; // in registers: the asm statements of pass 2 clobber memory
+    const double p[3] = {p_in[0], p_in[1], p_in[2]};
     const double radius = M.radius, lws = M.lws;
-    const int exact = M.exact;
     SRT_AS1 double *const rec = (SRT_AS1 double *)rec_flat; // device memory: global loads / stores, not flat ones
-    const int lane = threadIdx.x, g = lane >> 3, sub = lane & 7;
+    const int lane = threadIdx.x;
     const double r2 = radius * radius;
     const double pi_R = PI / radius;
-    constexpr int NT = J * (J + 1) / 2;
     double pg[8][3]; // the 8 points, wave-uniform
 #pragma unroll
     for (int gg = 0; gg < 8; ++gg)
 #pragma unroll
-      for (int k = 0; k < 3; ++k) pg[gg][k] = __shfl(p[k], 8 * gg);
+      for (int k = 0; k < 3; ++k) pg[gg][k] = uni(__shfl(p[k], 8 * gg));
     SRT_PHASE_BEGIN(list);
-    // ---- pass 1: count, cosine-window-weighted mean of the samples' nearest-neighbour distances (:296-303), for all
-    // 8 points from each sample; the sample and the centre's r, cos, sin go to the staging buffer
-    double hin8[8];
-    int cnt8[8];
-    {
-      double s8[8], v8[8];
-      int c8[8];
+    double s8[8], v8[8];
+    int c8[8];
 #pragma unroll
-      for (int gg = 0; gg < 8; ++gg) {
-        s8[gg] = v8[gg] = 0.0;
-        c8[gg] = 0;
-      }
-      // (one sample ahead: the next gather is in flight while this sample is worked on)
-      d2_t na = {0.0, 0.0}, nb = na, nc = na, nd = na;
-      if (lane < n_list) {
-        const SRT_AS1 d2_t *q = (const SRT_AS1 d2_t *)(M.gpts() + (size_t)list[lane] * 8);
+    for (int gg = 0; gg < 8; ++gg) {
+      s8[gg] = v8[gg] = 0.0;
+      c8[gg] = 0;
+    }
+    bool lv8[8];
+#pragma unroll
+    for (int gg = 0; gg < 8; ++gg) lv8[gg] = (livemask >> (8 * gg)) & 1ull; // wave-uniform
+    // (one sample ahead: the next gather is in flight while this sample is worked on)
+    d2_t na = {0.0, 0.0}, nb = na, nc = na, nd = na;
+    if (lane < n_list) {
+      const SRT_AS1 d2_t *q = (const SRT_AS1 d2_t *)(M.gpts() + (size_t)list[lane] * 8);
+      na = q[0], nb = q[1], nc = q[2], nd = q[3];
+    }
+#pragma unroll 1
+    for (int k = lane; k < n_list; k += 64) {
+      const d2_t qa = na, qb = nb, qc = nc, qd = nd;
+      if (k + 64 < n_list) {
+        const SRT_AS1 d2_t *q = (const SRT_AS1 d2_t *)(M.gpts() + (size_t)list[k + 64] * 8);
         na = q[0], nb = q[1], nc = q[2], nd = q[3];
       }
-#pragma unroll 1
-      for (int k = lane; k < n_list; k += 64) {
-        const d2_t qa = na, qb = nb, qc = nc, qd = nd;
-        if (k + 64 < n_list) {
-          const SRT_AS1 d2_t *q = (const SRT_AS1 d2_t *)(M.gpts() + (size_t)list[k + 64] * 8);
-          na = q[0], nb = q[1], nc = q[2], nd = q[3];
-        }
-        const double q0 = qa.x, q1 = qa.y, q2 = qb.x, q7 = qd.y;
-        double rc, ca, sa;
-        {
-          double d0 = q0 - pg[0][0], d1 = q1 - pg[0][1], d2 = q2 - pg[0][2];
-          double ss = d0 * d0 + d1 * d1 + d2 * d2;
-          rc = sqrt(ss);
-          sincos(rc * 2.0 * PI / radius / 2.0, &sa, &ca);
-          if ((livemask & 1ull) && ss < r2) {
-            double cw = 0.5 + 0.5 * ca;
-            s8[0] += cw;
-            v8[0] += cw * q7;
-            c8[0] += 1;
-          }
-        }
-#pragma unroll
-        for (int gg = 1; gg < 7; ++gg) {
-          double d0 = q0 - pg[gg][0], d1 = q1 - pg[gg][1], d2 = q2 - pg[gg][2];
-          double ss = d0 * d0 + d1 * d1 + d2 * d2;
-          if (((livemask >> (8 * gg)) & 1ull) && ss < r2) {
-            double da = (sqrt(ss) - rc) * pi_R, da2 = da * da;
-            double cd = 1.0 + da2 * (-0.5 + da2 * (1.0 / 24.0));
-            double sd = da * (1.0 + da2 * (-1.0 / 6.0 + da2 * (1.0 / 120.0)));
-            double cw = 0.5 + 0.5 * (ca * cd - sa * sd);
-            s8[gg] += cw;
-            v8[gg] += cw * q7;
-            c8[gg] += 1;
-          }
-        }
-        if (npts > 7) {
-          double d0 = q0 - pg[7][0], d1 = q1 - pg[7][1], d2 = q2 - pg[7][2];
-          double ss = d0 * d0 + d1 * d1 + d2 * d2;
-          if (((livemask >> 56) & 1ull) && ss < r2) {
-            double cw = 0.5 + 0.5 * cos(sqrt(ss) * 2.0 * PI / radius / 2.0);
-            s8[7] += cw;
-            v8[7] += cw * q7;
-            c8[7] += 1;
-          }
-        }
-        SRT_AS1 d2_t *r = (SRT_AS1 d2_t *)(rec + (size_t)k * REC);
-        r[0] = qa;
-        r[1] = qb;
-        r[2] = qc;
-        r[3] = d2_t{qd.x, 0.0};
-        r[4] = d2_t{rc, 0.0};
-        r[5] = d2_t{ca, sa};
+      const double q0 = qa.x, q1 = qa.y, q2 = qb.x, q7 = qd.y;
+      double rc, ca, sa;
+      {
+        double d0 = q0 - pg[0][0], d1 = q1 - pg[0][1], d2 = q2 - pg[0][2];
+        double ss = d0 * d0 + d1 * d1 + d2 * d2;
+        rc = fm::sqrt_pos(ss);
+        fm::sincos_0pi(rc * pi_R, sa, ca);
+        const bool in = lv8[0] && ss < r2;
+        const double cw = in ? 0.5 + 0.5 * ca : 0.0;
+        s8[0] += cw;
+        v8[0] += cw * q7;
+        c8[0] += in ? 1 : 0;
       }
-      SRT_PHASE(1);
+#pragma unroll
+      for (int gg = 1; gg < 8; ++gg) {
+        if (gg == 7 && !p7near) continue; // wave-uniform
+        double d0 = q0 - pg[gg][0], d1 = q1 - pg[gg][1], d2 = q2 - pg[gg][2];
+        double ss = d0 * d0 + d1 * d1 + d2 * d2;
+        const bool in = lv8[gg] && ss < r2;
+        double da = (fm::sqrt_pos(ss) - rc) * pi_R, da2 = da * da;
+        double cd = 1.0 + da2 * (-0.5 + da2 * (1.0 / 24.0));
+        double sd = da * (1.0 + da2 * (-1.0 / 6.0 + da2 * (1.0 / 120.0)));
+        const double cw = in ? 0.5 + 0.5 * (ca * cd - sa * sd) : 0.0;
+        s8[gg] += cw;
+        v8[gg] += cw * q7;
+        c8[gg] += in ? 1 : 0;
+      }
+      if (npts > 7 && !p7near) { // a far free point: its own cosine
+        double d0 = q0 - pg[7][0], d1 = q1 - pg[7][1], d2 = q2 - pg[7][2];
+        double ss = d0 * d0 + d1 * d1 + d2 * d2;
+        if (lv8[7] && ss < r2) {
+          double cw = 0.5 + 0.5 * cos(sqrt(ss) * 2.0 * PI / radius / 2.0);
+          s8[7] += cw;
+          v8[7] += cw * q7;
+          c8[7] += 1;
+        }
+      }
+      SRT_AS1 d2_t *r = (SRT_AS1 d2_t *)(rec + (size_t)k * REC);
+      r[0] = qa;
+      r[1] = qb;
+      r[2] = qc;
+      r[3] = d2_t{qd.x, 0.0};
+      r[4] = d2_t{rc, 0.0};
+      r[5] = d2_t{ca, sa};
+    }
+    SRT_PHASE(1);
+    SRT_LDS Pass1Out *o = pass1_out(list);
+#pragma unroll
+    for (int gg = 0; gg < 8; ++gg) {
+      const double ts = wave_sum(s8[gg]), tv = wave_sum(v8[gg]);
+      const int cn = (int)wave_sum((double)c8[gg]);
+      if (lane == 0) {
+        o->hin8[gg] = lws * (tv / ts);
+        o->cnt8[gg] = cn;
+      }
+    }
+    __syncthreads(); // block == one wave: the records and the sums written above are read by other lanes next
+    SRT_PHASE(2);
+  }
+
+  // All eight half-weights of every sample of the list (see above); usemask: the reference's weight > 1e-16 mask (:316-317)
+  template <int J>
+  __device__ __noinline__ void sf_weights(const double (&p_in)[3], bool live, unsigned long long livemask, int npts, int n_list,
+                                          SRT_LDS const int *list, double *rec_flat, double dmax6, double d7, bool p7near,
+                                          bool usemask) const {
+    const ScatteredModel M = uniform_copy();
+    const double p[3] = {p_in[0], p_in[1], p_in[2]};
+    const double radius = M.radius;
+    SRT_AS1 double *const rec = (SRT_AS1 double *)rec_flat;
+    const int lane = threadIdx.x, g = lane >> 3;
+    const double r2 = radius * radius, pi_R = PI / radius, reps = radius * 5.0e-16;
+    SRT_PHASE_BEGIN(list);
+    SRT_LDS const Pass1Out *o = pass1_out(list);
+    double hin8[8], pg[8][3];
+    bool fit8[8], lv8[8];
+#pragma unroll
+    for (int gg = 0; gg < 8; ++gg) {
+      hin8[gg] = uni(o->hin8[gg]);
+      lv8[gg] = (livemask >> (8 * gg)) & 1ull;
+      fit8[gg] = lv8[gg] && gg < npts && uni(o->cnt8[gg]) >= J;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) pg[gg][k] = uni(__shfl(p[k], 8 * gg));
+    }
+    // the centre's h against each point's: eta_g = h_c / h_g - 1
+    double eta8[8], etamax6 = 0.0;
+#pragma unroll
+    for (int gg = 0; gg < 8; ++gg) {
+      eta8[gg] = (hin8[0] - hin8[gg]) / hin8[gg];
+      if (gg < 7 && fit8[gg]) etamax6 = fmax(etamax6, fabs(eta8[gg]));
+    }
+    const double eta7 = fit8[7] ? fabs(eta8[7]) : 0.0;
+    const bool base_ok = M.exact != 1 && uni(o->cnt8[0]) >= 1 && hin8[0] > 0.0 && etamax6 <= 1.0e-3;
+    const double sh = base_ok ? exp(-1.1 * log(hin8[0] / 4.0)) : 0.0; // (h_c / 4)**-1.1: u_c = a sh
+    // the points' offsets from the centre: point 1 + 2a / 2 + 2a = centre +- da e_a, point 7 = centre + (o7x, o7y, o7z)
+    const double da3[3] = {pg[1][0] - pg[0][0], pg[3][1] - pg[0][1], pg[5][2] - pg[0][2]};
+    const double mda3[3] = {pg[2][0] - pg[0][0], pg[4][1] - pg[0][1], pg[6][2] - pg[0][2]};
+    const double o7[3] = {pg[7][0] - pg[0][0], pg[7][1] - pg[0][1], pg[7][2] - pg[0][2]};
+    const double o7sq = o7[0] * o7[0] + o7[1] * o7[1] + o7[2] * o7[2];
+    // (one record ahead)
+    d2_t n0 = {0.0, 0.0}, n1 = n0, n4 = n0, n5 = n0;
+    if (lane < n_list) {
+      const SRT_AS1 d2_t *r = (const SRT_AS1 d2_t *)(rec + (size_t)lane * REC);
+      n0 = r[0], n1 = r[1], n4 = r[4], n5 = r[5];
+    }
+#pragma unroll 1
+    for (int k = lane; k < n_list; k += 64) {
+      const d2_t c0 = n0, c1 = n1, c4 = n4, c5 = n5;
+      if (k + 64 < n_list) {
+        const SRT_AS1 d2_t *r = (const SRT_AS1 d2_t *)(rec + (size_t)(k + 64) * REC);
+        n0 = r[0], n1 = r[1], n4 = r[4], n5 = r[5];
+      }
+      const double q0 = c0.x, q1 = c0.y, q2 = c1.x, rc = c4.x, ca = c5.x, sa = c5.y;
+      const double dc[3] = {q0 - pg[0][0], q1 - pg[0][1], q2 - pg[0][2]};
+      const double ssc = dc[0] * dc[0] + dc[1] * dc[1] + dc[2] * dc[2];
+      const double xr = rc + reps;
+      const double a11 = xr * fm::exp_any(0.1 * fm::log_pos(xr));
+      const double inv = fdiv(1.0, xr), inv2 = inv * inv;
+      const double u = a11 * sh;
+      const double E = fm::exp_any(-u);
+      double tb6 = dmax6 * inv, tb7 = d7 * inv;
+      tb6 = tb6 + etamax6 * (1.0 + tb6);
+      tb7 = tb7 + eta7 * (1.0 + tb7);
+      const bool dir6 = !(base_ok && tb6 <= 1.0e-3 && u * 1.2 * tb6 <= 1.0e-3);
+      const bool dir7 = dir6 || !(p7near && tb7 <= 1.0e-3 && u * 1.2 * tb7 <= 1.0e-3);
+      double w8[8];
 #pragma unroll
       for (int gg = 0; gg < 8; ++gg) {
-        double ts = wave_sum(s8[gg]), tv = wave_sum(v8[gg]);
-        cnt8[gg] = (int)wave_sum((double)c8[gg]);
-        hin8[gg] = lws * (tv / ts);
+        // t = r_g^2 - r_c^2 from the offset itself
+        double t;
+        if (gg == 0) t = 0.0;
+        else if (gg == 7) t = o7sq - 2.0 * (o7[0] * dc[0] + o7[1] * dc[1] + o7[2] * dc[2]);
+        else {
+          const int ax = (gg - 1) >> 1;
+          const double dl = (gg & 1) ? da3[ax] : mda3[ax];
+          t = dl * (dl - 2.0 * dc[ax]);
+        }
+        const bool in = fit8[gg] && ssc + t < r2; // strictly inside (kdtree_mod.f95:171)
+        double e;
+        if (gg == 0) {
+          e = E * (0.5 + 0.5 * ca);
+        } else {
+          const double eps = t * inv2;
+          const double dr = (0.5 * t * inv) * (1.0 + eps * (-0.25 + eps * (0.125 + eps * (-0.078125 + eps * 0.0546875))));
+          const double tau = (dr * inv) * (1.0 + eta8[gg]) + eta8[gg];
+          const double sp = tau * (1.1 + tau * (0.055 + tau * (-0.0165 + tau * (0.0078375 + tau * -0.00454575))));
+          const double du = u * sp;
+          const double X = 1.0 + du * (-1.0 + du * (0.5 + du * (-1.0 / 6.0 + du * (1.0 / 24.0 + du * (-1.0 / 120.0 + du * (1.0 / 720.0))))));
+          const double dan = dr * pi_R, da2 = dan * dan;
+          const double cd = 1.0 + da2 * (-0.5 + da2 * (1.0 / 24.0));
+          const double sd = dan * (1.0 + da2 * (-1.0 / 6.0 + da2 * (1.0 / 120.0)));
+          e = E * X * (0.5 + 0.5 * (ca * cd - sa * sd));
+        }
+        w8[gg] = in ? e : 0.0;
       }
-    }
-    double hin = hin8[0];
-    int count = cnt8[0];
+      if (dir7) { // rare, per lane: etainv() itself at the points that cannot take the series
+#pragma unroll 1
+        for (int gg = 0; gg < 8; ++gg) {
+          if (gg < 7 && !dir6) continue;
+          double px = pg[0][0], py = pg[0][1], pz = pg[0][2], hg = hin8[0];
+          bool fg = fit8[0];
 #pragma unroll
-    for (int gg = 1; gg < 8; ++gg) {
-      hin = (g == gg) ? hin8[gg] : hin;
-      count = (g == gg) ? cnt8[gg] : count;
-    }
-    const bool fit = live && count >= J; // else status 2: too few samples (lsinterp_mod.f95:262-264)
-    // the centre's h against this point's: eta = h_c / h_g - 1
-    const double eta = (hin8[0] - hin) / hin;
-    double etamax = (fit && g < 7) ? fabs(eta) : 0.0;
-    etamax = fmax(etamax, __shfl_xor(etamax, 8));
-    etamax = fmax(etamax, __shfl_xor(etamax, 16));
-    etamax = fmax(etamax, __shfl_xor(etamax, 32));
-    SRT_PHASE(2);
-    const bool base_ok = exact != 1 && cnt8[0] >= 1 && hin8[0] > 0.0 && etamax <= 1.0e-3;
-    // ---- base pass: the centre's x**1.1 and exp; which samples are direct; the free point's weight
-    {
-      const double reps = radius * 5.0e-16;
-      const double hc = hin8[0] / 4.0;
-      bool any_direct = false;
-      double nrc = 0.0, nq0 = 0.0, nq1 = 0.0, nq2 = 0.0; // (one record ahead, as in pass 1)
-      if (lane < n_list) {
-        const SRT_AS1 double *r = rec + (size_t)lane * REC;
-        nrc = r[8], nq0 = r[0], nq1 = r[1], nq2 = r[2];
-      }
-#pragma unroll 1
-      for (int k = lane; k < n_list; k += 64) {
-        SRT_AS1 double *r = rec + (size_t)k * REC;
-        const double rc = nrc, q0 = nq0, q1 = nq1, q2 = nq2;
-        if (k + 64 < n_list) {
-          const SRT_AS1 double *rn = rec + (size_t)(k + 64) * REC;
-          nrc = rn[8], nq0 = rn[0], nq1 = rn[1], nq2 = rn[2];
-        }
-        const double xr = rc + reps;
-        const double x = xr / hc;
-        const double u = x * exp(0.1 * log(x));
-        const double E = exp(-u);
-        const double inv = 1.0 / xr;
-        double tb = dmax * inv;
-        tb = tb + etamax * (1.0 + tb);
-        const bool series = base_ok && tb <= 1.0e-3 && u * 1.2 * tb <= 1.0e-3;
-        any_direct = any_direct || !series;
-        r[7] = series ? 0.0 : 1.0;
-        r[9] = inv;
-        r[12] = u;
-        r[13] = E;
-        if (npts > 7) {
-          double d0 = q0 - pg[7][0], d1 = q1 - pg[7][1], d2 = q2 - pg[7][2];
-          double ss = d0 * d0 + d1 * d1 + d2 * d2;
-          r[15] = (((livemask >> 56) & 1ull) && ss < r2) ? M.etainv_at(ss, hin8[7]) : 0.0;
-        }
-      }
-      if (__any(any_direct)) { // rare: wave-uniform trips so that the shuffles see every lane
-#pragma unroll 1
-        for (int k0 = 0; k0 < n_list; k0 += 64) {
-          const int k = k0 + lane;
-          SRT_AS1 double *r = rec + (size_t)(k < n_list ? k : 0) * REC;
-          const bool direct = k < n_list && r[7] != 0.0;
-          if (!__any(direct)) continue;
-          const double q0 = r[0], q1 = r[1], q2 = r[2];
-#pragma unroll 1
-          for (int gg = 0; gg < 7; ++gg) {
-            const double px = __shfl(p[0], 8 * gg), py = __shfl(p[1], 8 * gg), pz = __shfl(p[2], 8 * gg);
-            const double hg = __shfl(hin, 8 * gg);
-            const bool lv = (livemask >> (8 * gg)) & 1ull;
-            if (direct) {
-              double d0 = q0 - px, d1 = q1 - py, d2 = q2 - pz;
-              double ss = d0 * d0 + d1 * d1 + d2 * d2;
-              r[8 + gg] = (lv && ss < r2) ? M.etainv_at(ss, hg) : 0.0;
-            }
+          for (int t = 1; t < 8; ++t) {
+            px = gg == t ? pg[t][0] : px, py = gg == t ? pg[t][1] : py, pz = gg == t ? pg[t][2] : pz;
+            hg = gg == t ? hin8[t] : hg;
+            fg = gg == t ? fit8[t] : fg;
           }
+          const double e0 = q0 - px, e1 = q1 - py, e2 = q2 - pz;
+          const double ss = e0 * e0 + e1 * e1 + e2 * e2;
+          const double e = (fg && ss < r2) ? M.etainv_at(ss, hg) : 0.0;
+#pragma unroll
+          for (int t = 0; t < 8; ++t) w8[t] = gg == t ? e : w8[t];
         }
       }
+#pragma unroll
+      for (int gg = 0; gg < 8; ++gg) w8[gg] = (usemask && !(w8[gg] > 1.0e-16)) ? 0.0 : 0.5 * w8[gg]; // :316-317
+      SRT_AS1 d2_t *r = (SRT_AS1 d2_t *)(rec + (size_t)k * REC);
+      r[4] = d2_t{w8[0], w8[1]};
+      r[5] = d2_t{w8[2], w8[3]};
+      r[6] = d2_t{w8[4], w8[5]};
+      r[7] = d2_t{w8[6], w8[7]};
     }
-    __syncthreads(); // block == one wave: the records written above are read by other lanes below
+    __syncthreads(); // block == one wave: the weights written above are read by other lanes next
     SRT_PHASE(3);
-    // ---- pass 2: normal equations.  Group g walks the records for point g, its 8 lanes splitting them; no
-    // transcendental function and no branch in the loop
+  }
+
+  // Normal equations of this group's point from the finished records, and the solve
+  template <int J>
+  __device__ __noinline__ Fit4 sf_sums(const double (&p_in)[3], bool fit, int n_list, SRT_LDS const int *list, double *rec_flat,
+                                       int &kept_out) const {
+    Fit4 fi;
+    const double p[3] = {p_in[0], p_in[1], p_in[2]}; // in registers: the asm statements below clobber memory
+    SRT_AS1 double *const rec = (SRT_AS1 double *)rec_flat;
+    const int lane = threadIdx.x, g = lane >> 3, sub = lane & 7;
+    constexpr int NT = J * (J + 1) / 2;
+    SRT_PHASE_BEGIN(list);
     constexpr bool O3 = J == 20; // order 3: all sums live in S20 (84 moments + 80), A is only formed inside its solve
-    double A[O3 ? 1 : NT], b[O3 ? 1 : J][4];
+    double A[(O3 || J == 10) ? 1 : NT], b[O3 ? 1 : J][4];
     double Mm[J == 10 ? Moments::N : 1]; // order 2: the 35 moments stand in for the 55 entries of A while summing
     typename std::conditional<O3, Sums20, int>::type S20;
     int kept = 0;
-    bool usemask = true, todo = fit;
-    const double eta1 = 1.0 + eta;
-    const int slot = (g == 7) ? 15 : 8 + g;
-    const bool group7 = g == 7;
-#pragma unroll 1
-    for (int attempt = 0; attempt < 2; ++attempt) {
-      if (!__any(todo)) break; // wave-uniform
-      if (todo) {
-        if constexpr (O3) S20.zero();
+    if constexpr (O3) S20.zero();
 #pragma unroll
-        for (int t = 0; t < (O3 ? 1 : NT); ++t) A[t] = 0.0;
+    for (int t = 0; t < ((O3 || J == 10) ? 1 : NT); ++t) A[t] = 0.0;
 #pragma unroll
-        for (int t = 0; t < (J == 10 ? Moments::N : 1); ++t) Mm[t] = 0.0;
+    for (int t = 0; t < (J == 10 ? Moments::N : 1); ++t) Mm[t] = 0.0;
 #pragma unroll
-        for (int a = 0; a < (O3 ? 1 : J); ++a)
+    for (int a = 0; a < (O3 ? 1 : J); ++a)
 #pragma unroll
-          for (int s = 0; s < 4; ++s) b[a][s] = 0.0;
-        kept = 0;
-      }
-      double pw2 = 0.0, pd0 = 0.0, pd1 = 0.0, pd2 = 0.0, pln[4] = {0.0, 0.0, 0.0, 0.0}; // the record waiting to be folded in
-      auto fold = [&](double w2, double d0, double d1, double d2, const double (&ln)[4]) {
-        if constexpr (O3) {
-          S20.fold(w2, d0, d1, d2, ln);
-        } else if constexpr (J == 10) {
-          const double dd[3] = {d0, d1, d2};
-          double mono[Moments::N], m[10];
-          Moments::monomials(mono, dd, std::make_integer_sequence<int, Moments::N - 1>{});
-          Mm[0] += w2;
+      for (int s = 0; s < 4; ++s) b[a][s] = 0.0;
+    auto fold = [&](double w2, double d0, double d1, double d2, const double (&ln)[4]) {
+      if constexpr (O3) {
+        S20.fold(w2, d0, d1, d2, ln);
+      } else if constexpr (J == 10) {
+        // the weight is folded into the monomials as they are built (w, w x, w x^2 .. : the same 34 products), so the
+        // moments take an addition each and the right-hand sums find their w m_a ready made
+        const double dd[3] = {d0, d1, d2};
+        double wm[Moments::N], m[10];
+        wm[0] = w2;
+        Moments::monomials_from(wm, dd, std::make_integer_sequence<int, Moments::N - 1>{});
 #pragma unroll
-          for (int i = 1; i < Moments::N; ++i) Mm[i] += w2 * mono[i];
-          Moments::firsts(mono, m, std::make_integer_sequence<int, 10>{}); // m_a: the same products as monomials<10>()
+        for (int i = 0; i < Moments::N; ++i) Mm[i] += wm[i];
+        Moments::firsts(wm, m, std::make_integer_sequence<int, 10>{}); // w m_a
 #pragma unroll
-          for (int a = 0; a < 10; ++a) {
-            double wa = w2 * m[a];
+        for (int a = 0; a < 10; ++a)
 #pragma unroll
-            for (int s = 0; s < 4; ++s) b[a][s] += wa * ln[s];
-          }
-        } else {
-          double m[J];
-          monomials<J>(d0, d1, d2, m);
-          int t = 0;
+          for (int s = 0; s < 4; ++s) b[a][s] += m[a] * ln[s];
+      } else {
+        double m[J];
+        monomials<J>(d0, d1, d2, m);
+        int t = 0;
 #pragma unroll
-          for (int a = 0; a < J; ++a) {
-            double wa = w2 * m[a];
+        for (int a = 0; a < J; ++a) {
+          double wa = w2 * m[a];
 #pragma unroll
-            for (int cI = a; cI < J; ++cI) A[t++] += wa * m[cI];
+          for (int cI = a; cI < J; ++cI) A[t++] += wa * m[cI];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) b[a][s] += wa * ln[s];
-          }
+          for (int s = 0; s < 4; ++s) b[a][s] += wa * ln[s];
         }
+      }
+    };
+    // The records come back through a ring of NBUF 64-record buffers in LDS (the list area: the list is dead by now),
+    // filled by LDS-DMA NBUF - 1 buffers ahead -- the staging buffers of the CU's waves do not stay in L2 (the scans of
+    // the other waves stream through it).
+    // Buffer layout: [16-byte chunk t of the record][record] -- DMA instruction t moves chunk t of 64 records (lane =
+    // record), and the 8 lanes of a group read 8 neighbouring 16-byte slots (all 8 groups the same ones: broadcast).
+    {
+      const int nchunk = (n_list + 63) >> 6; // wave-uniform
+      SRT_AS3 char *const ring = (SRT_AS3 char *)list;
+      auto issue = [&](int c) {
+        int r = c * 64 + lane;
+        r = r < n_list ? r : n_list - 1;
+        const SRT_AS1 char *src = (const SRT_AS1 char *)(rec + (size_t)r * REC);
+        SRT_AS3 char *dst = ring + (c % NBUF) * 8192;
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+          __builtin_amdgcn_global_load_lds((const SRT_AS1 void *)(src + 16 * t), (SRT_AS3 void *)(dst + 1024 * t), 16, 0, 0);
       };
-      // The records come back through a ring of four 64-record buffers in LDS (the list area: the list is dead by now),
-      // filled by LDS-DMA three buffers ahead -- the staging buffers of the CU's waves do not stay in L2 (the scans of
-      // the other waves stream through it), and one wave per SIMD has nothing else to hide that latency behind.
-      // Buffer layout: [16-byte chunk t of the record][record] -- DMA instruction t moves chunk t of 64 records (lane =
-      // record), and the 8 lanes of a group read 8 neighbouring 16-byte slots (all 8 groups the same ones: broadcast).
-      {
-        const int nchunk = (n_list + 63) >> 6; // wave-uniform
-        SRT_AS3 char *const ring = (SRT_AS3 char *)list;
-        auto issue = [&](int c) {
-          int r = c * 64 + lane;
-          r = r < n_list ? r : n_list - 1;
-          const SRT_AS1 char *src = (const SRT_AS1 char *)(rec + (size_t)r * REC);
-          SRT_AS3 char *dst = ring + (c & 3) * 8192;
-#pragma unroll
-          for (int t = 0; t < 8; ++t)
-            __builtin_amdgcn_global_load_lds((const SRT_AS1 void *)(src + 16 * t), (SRT_AS3 void *)(dst + 1024 * t), 16, 0, 0);
-        };
-        if (__any(todo)) {
-          for (int c = 0; c < 3 && c < nchunk; ++c) issue(c);
-        }
-        const unsigned ring0 = (unsigned)(unsigned long long)ring + (unsigned)(sub * 16);
-        const unsigned slot_off = (unsigned)((slot >> 1) * 1024 + (slot & 1) * 8);
+      const bool any = __any(fit);
+      if (any) {
+        for (int c = 0; c < NBUF - 1 && c < nchunk; ++c) issue(c);
+      }
+      const int slot = (g == 7) ? 15 : 8 + g;
+      const unsigned ring0 = (unsigned)(unsigned long long)ring + (unsigned)(sub * 16);
+      const unsigned slot_off = (unsigned)((slot >> 1) * 1024 + (slot & 1) * 8);
 #pragma unroll 1
-        for (int c = 0; c < nchunk && __any(todo); ++c) {
-          if (c + 3 < nchunk) issue(c + 3);
-          const int ahead = nchunk - 1 - c; // buffers that may still be in flight while this one is read
-          if (ahead >= 3) InterpModel::wait_vm<24>();
-          else if (ahead == 2) InterpModel::wait_vm<16>();
-          else if (ahead == 1) InterpModel::wait_vm<8>();
-          else InterpModel::wait_vm<0>();
-          if (todo) {
-            const unsigned cbase = ring0 + (unsigned)((c & 3) * 8192);
+      for (int c = 0; c < nchunk && any; ++c) {
+        if (c + NBUF - 1 < nchunk) issue(c + NBUF - 1); // (into the buffer read on the previous trip: its reads have all returned)
+        const int ahead = min(nchunk - 1 - c, NBUF - 1); // buffers that may still be in flight while this one is read
+        if (ahead >= 3) InterpModel::wait_vm<24>();
+        else if (ahead == 2) InterpModel::wait_vm<16>();
+        else if (ahead == 1) InterpModel::wait_vm<8>();
+        else InterpModel::wait_vm<0>();
+        if (fit) {
+          const unsigned cbase = ring0 + (unsigned)((c % NBUF) * 8192);
 #pragma unroll 1
-            for (int i = 0; i < 8; ++i) {
-              const int k = c * 64 + 8 * i + sub;
-              const unsigned ra = cbase + (unsigned)(i * 128);
-              d2_t c0, c1, c2, c3, c4, c5, c6;
-              double wdir;
-              // (inline asm: the compiler's wait-count pass would make an LDS load it can see wait for ALL DMA in flight)
-              asm volatile("ds_read_b128 %0, %8\n\t"
-                           "ds_read_b128 %1, %8 offset:1024\n\t"
-                           "ds_read_b128 %2, %8 offset:2048\n\t"
-                           "ds_read_b128 %3, %8 offset:3072\n\t"
-                           "ds_read_b128 %4, %8 offset:4096\n\t"
-                           "ds_read_b128 %5, %8 offset:5120\n\t"
-                           "ds_read_b128 %6, %8 offset:6144\n\t"
-                           "ds_read_b64 %7, %9\n\t"
-                           "s_waitcnt lgkmcnt(0)"
-                           : "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(c3), "=&v"(c4), "=&v"(c5), "=&v"(c6), "=&v"(wdir)
-                           : "v"(ra), "v"(ra + slot_off)
-                           : "memory");
-              // the sums of the PREVIOUS record (independent of this record's weight, which is one long dependent chain)
-              fold(pw2, pd0, pd1, pd2, pln);
-              const double d0 = c0.x - p[0], d1 = c0.y - p[1], d2 = c1.x - p[2];
-              const double ss = d0 * d0 + d1 * d1 + d2 * d2;
-              // series from the centre's values ([8] r_c [9] inv [10] ca [11] sa [12] u_c [13] E_c)
-              const double dr = sqrt(ss) - c4.x;
-              const double ti = dr * c4.y;
-              const double tau = ti * eta1 + eta;
-              const double sp = tau * (1.1 + tau * (0.055 + tau * (-0.0165 + tau * (0.0078375 + tau * -0.00454575))));
-              const double du = c6.x * sp;
-              const double X = 1.0 + du * (-1.0 + du * (0.5 + du * (-1.0 / 6.0 + du * (1.0 / 24.0 + du * (-1.0 / 120.0 + du * (1.0 / 720.0))))));
-              const double da = dr * pi_R, da2 = da * da;
-              const double cd = 1.0 + da2 * (-0.5 + da2 * (1.0 / 24.0));
-              const double sd = da * (1.0 + da2 * (-1.0 / 6.0 + da2 * (1.0 / 120.0)));
-              const double win = 0.5 + 0.5 * (c5.x * cd - c5.y * sd);
-              double e = c6.y * X * win;
-              e = (group7 || c3.y != 0.0) ? wdir : e;
-              // strictly inside (kdtree_mod.f95:171; the shared list holds a superset); :316-317
-              const bool use = k < n_list && ss < r2 && !(usemask && !(e > 1.0e-16));
-              kept += use ? 1 : 0;
-              // (this record waits for the next trip's reads: same records in the same order, the sums do not change)
-              pw2 = use ? 0.5 * e : 0.0;
-              pd0 = d0, pd1 = d1, pd2 = d2;
-              pln[0] = c1.y, pln[1] = c2.x, pln[2] = c2.y, pln[3] = c3.x;
-            }
+          for (int i = 0; i < 8; ++i) {
+            const int k = c * 64 + 8 * i + sub;
+            const unsigned ra = cbase + (unsigned)(i * 128);
+            d2_t c0, c1, c2, c3;
+            double w2;
+            // (inline asm: the compiler's wait-count pass would make an LDS load it can see wait for ALL DMA in flight)
+            asm volatile("ds_read_b128 %0, %5\n\t"
+                         "ds_read_b128 %1, %5 offset:1024\n\t"
+                         "ds_read_b128 %2, %5 offset:2048\n\t"
+                         "ds_read_b64 %3, %5 offset:3072\n\t"
+                         "ds_read_b64 %4, %6\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(c3.x), "=&v"(w2)
+                         : "v"(ra), "v"(ra + slot_off)
+                         : "memory");
+            w2 = k < n_list ? w2 : 0.0;
+            kept += w2 != 0.0 ? 1 : 0;
+            const double ln[4] = {c1.y, c2.x, c2.y, c3.x};
+            fold(w2, c0.x - p[0], c0.y - p[1], c1.x - p[2], ln);
           }
         }
-        if (todo) {
-          fold(pw2, pd0, pd1, pd2, pln); // the last record
-          pw2 = 0.0;
-        }
-        InterpModel::wait_vm<0>();
       }
-      const int kept_all = group_sum(kept);
-      // threw out too many samples: use them all (:319-323)
-      todo = todo && kept_all < J;
-      if (todo) usemask = false;
+      InterpModel::wait_vm<0>();
     }
+    kept_out = group_sum(kept);
     SRT_PHASE(4);
     // combine the 8 lanes' partial sums and solve
     fi.v[0] = fi.v[1] = fi.v[2] = fi.v[3] = 0.0;
@@ -1005,15 +1164,32 @@ struct ScatteredModel {
             for (int s = 0; s < 4; ++s) fi.v[s] = f4[s];
           }
         }
-      } else {
-        if constexpr (J == 10) {
+      } else if constexpr (J == 10) {
+        SRT_LDS double *area = (SRT_LDS double *)const_cast<SRT_LDS int *>(list) + 80 * g; // (the ring is dead by now)
 #pragma unroll
-          for (int t = 0; t < Moments::N; ++t) Mm[t] = group_sum(Mm[t]);
-          Moments::expand(Mm, A, std::make_integer_sequence<int, 55>{});
-        } else {
-#pragma unroll
-          for (int t = 0; t < NT; ++t) A[t] = group_sum(A[t]);
+        for (int t = 0; t < Moments::N; ++t) {
+          const double v = group_sum(Mm[t]);
+          if (sub == (t & 7)) area[t] = v;
         }
+#pragma unroll
+        for (int a = 0; a < 10; ++a)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const double v = group_sum(b[a][s]);
+            if (sub == ((4 * a + s) & 7)) area[35 + 4 * a + s] = v;
+          }
+        __syncthreads(); // block == one wave: the totals written above are read by the group's other lanes below
+        if (fit) {
+          double f4[4];
+          if (solve10_parked(area, f4) == 0) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) fi.v[s] = f4[s];
+          }
+        }
+        __syncthreads(); // (the area is list space again)
+      } else {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) A[t] = group_sum(A[t]);
 #pragma unroll
         for (int a = 0; a < J; ++a)
 #pragma unroll
@@ -1028,6 +1204,25 @@ struct ScatteredModel {
       }
     }
     SRT_PHASE(5);
+    return fi;
+  }
+
+  template <int J>
+  __device__ __forceinline__ Fit4 shared_fit(const double (&p)[3], bool live, unsigned long long livemask, int npts, int n_list,
+                                             SRT_LDS const int *list, double *rec, double dmax6, double d7, bool p7near) const {
+    const int g = threadIdx.x >> 3;
+    sf_pass1(p, livemask, npts, n_list, list, rec, p7near);
+    // this group's fit exists iff its point has at least J samples (else status 2: too few samples, lsinterp_mod.f95:262-264)
+    const bool fit = live && pass1_out(list)->cnt8[g] >= J;
+    sf_weights<J>(p, live, livemask, npts, n_list, list, rec, dmax6, d7, p7near, true);
+    int kept = 0;
+    Fit4 fi = sf_sums<J>(p, fit, n_list, list, rec, kept);
+    const bool again = fit && kept < J; // threw out too many samples: use them all (:319-323)
+    if (__any(again)) {                 // (wave-uniform; rare)
+      sf_weights<J>(p, live, livemask, npts, n_list, list, rec, dmax6, d7, p7near, false);
+      const Fit4 f2 = sf_sums<J>(p, again, n_list, list, rec, kept);
+      if (again) fi = f2;
+    }
     return fi;
   }
   // The own-list path: the stencil straddles a grid cell, is too wide for the series, or the shared list would not
@@ -1154,12 +1349,109 @@ struct ScatteredModel {
     return fi;
   }
 
+  // ---- candidate blocks ----------------------------------------------------------------------------------------
+  // A ray moves ~4 % of the search radius per step (BASELINE config[4]), so consecutive stencils of a lane -- the six of
+  // one attempt and those of the next steps -- see almost the same samples.  Each lane of the trace kernel therefore owns
+  // a candidate block in device memory: every sample within radius * (1 + bmargin) of the block's centre C (fp64 test, made
+  // when the block is built by a scan of the 27 cells around C: the grid's cell edge is radius * (1 + bmargin)), stored as
+  // {float(q - C), sample index} = 16 bytes.  A stencil whose points all lie within bmargin * radius of C (less a slack for
+  // the float32 coordinates) finds its candidates by filtering the block -- one coalesced 16-byte load per candidate and a
+  // float32 distance test against radius + stencil extent + slack, a superset of what every point's own exact test
+  // (shared_fit, passes 1 and 2) accepts -- instead of scanning the cells: ~1.4 x the neighbour count instead of ~6.5 x.
+  // A block is a function of its centre alone; the trace kernel forgets a lane's block when the lane is given a new ray
+  // (new_ray_hook), so a ray's arithmetic depends on its own history only.
+  struct Block {
+    double C[3];
+    int count; // -1: none
+  };
+  __device__ __forceinline__ static Block load_header(SRT_LDS const int *lists, int j) {
+    SRT_LDS const double *h = (SRT_LDS const double *)lists + LDS_HDR + 4 * j;
+    Block b;
+    b.C[0] = h[0], b.C[1] = h[1], b.C[2] = h[2];
+    b.count = ((SRT_LDS const int *)(h + 3))[0];
+    return b;
+  }
+  // scan the 27 cells around the centre pc (all lanes) into `blk`; returns the entry count, -1 if the block cannot hold them
+  __device__ __forceinline__ int build_block(const double (&pc)[3], const Rows &Rc, SRT_AS1 f4_t *blk) const {
+    const int lane = threadIdx.x;
+    const double Rb = radius * (1.0 + bmargin), Rb2 = Rb * Rb;
+    int lo9[9], hi9[9], maxlen = 0;
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+      row_range(Rc, r, lo9[r], hi9[r]);
+      maxlen = max(maxlen, hi9[r] - lo9[r]);
+    }
+    const SRT_AS1 double *xs = gxyz(), *ys = xs + npts, *zs = ys + npts;
+    int idxn[9];
+    double qxn[9], qyn[9], qzn[9];
+    auto fetch = [&](int t0) {
+#pragma unroll
+      for (int r = 0; r < 9; ++r) {
+        const int i = lo9[r] + t0 + lane;
+        idxn[r] = i < hi9[r] ? i : -1;
+        const int ic = idxn[r] < 0 ? 0 : idxn[r];
+        qxn[r] = xs[ic], qyn[r] = ys[ic], qzn[r] = zs[ic];
+      }
+    };
+    int n = 0;
+    if (maxlen > 0) fetch(0);
+#pragma unroll 1
+    for (int t0 = 0; t0 < maxlen; t0 += 64) {
+      if (n > BLOCK_CAP - TRIP_MAX) return -1;
+      int idx[9];
+      double qx[9], qy[9], qz[9];
+#pragma unroll
+      for (int r = 0; r < 9; ++r) idx[r] = idxn[r], qx[r] = qxn[r], qy[r] = qyn[r], qz[r] = qzn[r];
+      if (t0 + 64 < maxlen) fetch(t0 + 64);
+#pragma unroll
+      for (int r = 0; r < 9; ++r) {
+        const double d0 = qx[r] - pc[0], d1 = qy[r] - pc[1], d2 = qz[r] - pc[2];
+        const bool acc = idx[r] >= 0 && d0 * d0 + d1 * d1 + d2 * d2 < Rb2;
+        const unsigned long long m = __ballot(acc);
+        if (acc) blk[n + __popcll(m & ((1ull << lane) - 1ull))] = f4_t{(float)d0, (float)d1, (float)d2, __int_as_float(idx[r])};
+        n = __builtin_amdgcn_readfirstlane(n + __popcll(m));
+      }
+    }
+    return n;
+  }
+  // candidates of a stencil centred at pc from a block: entries within rs of pc (float32 test, rs includes the slack)
+  __device__ __forceinline__ int filter_block(const Block &B, const double (&pc)[3], double rs, const SRT_AS1 f4_t *blk,
+                                              SRT_LDS int *lists) const {
+    const int lane = threadIdx.x;
+    const float px = (float)(pc[0] - B.C[0]), py = (float)(pc[1] - B.C[1]), pz = (float)(pc[2] - B.C[2]);
+    const float rs2 = (float)rs * (float)rs;
+    int n_list = 0;
+    const int last = B.count - 1;
+    // (the whole of a typical block -- ~1.4 x the neighbour count, a few hundred entries -- is in flight at once)
+#pragma unroll 1
+    for (int t0 = 0; t0 < B.count; t0 += 1024) {
+      f4_t e[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int i = t0 + 64 * u + lane;
+        e[u] = blk[i < last ? i : last];
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        if (t0 + 64 * u > last) break; // wave-uniform
+        const int i = t0 + 64 * u + lane;
+        const float d0 = e[u].x - px, d1 = e[u].y - py, d2 = e[u].z - pz;
+        const bool acc = i <= last && d0 * d0 + d1 * d1 + d2 * d2 < rs2;
+        const unsigned long long m = __ballot(acc);
+        if (acc) lists[n_list + __popcll(m & ((1ull << lane) - 1ull))] = __float_as_int(e[u].w);
+        n_list = __builtin_amdgcn_readfirstlane(n_list + __popcll(m));
+      }
+    }
+    return n_list;
+  }
+
   // out[8][4] (per lane): densities at the lane's stencil points 0..npts-1 (point 7 = extra).  All 64 lanes call
   // together; lanes with need == false are not served (their out is left untouched).
   //
-  // Per owner lane: its <= 8 points go to the 8 groups of 8 lanes.  Normally all points share the centre's grid cell
-  // and the six offsets are tiny against the radius: then ONE scan of the centre's 27 cells by all 64 lanes (radius
-  // widened by the stencil's extent) yields a superset list in LDS and shared_fit() does the rest; otherwise own_fit().
+  // Per owner lane: its <= 8 points go to the 8 groups of 8 lanes.  Normally the six offsets are tiny against the radius:
+  // then ONE candidate list for the whole stencil (radius widened by the stencil's extent) is made in LDS -- from the
+  // lane's candidate block (trace kernel), else by a scan of the centre's 27 cells by all 64 lanes when the points share a
+  // grid cell -- and shared_fit() does the rest; otherwise own_fit().
   template <int J>
   __device__ __noinline__ void coop_stencil(const double *c, const double *d, const double *extra, int npts, bool need,
                                             double *out, SRT_LDS int *lists) const {
@@ -1169,6 +1461,7 @@ struct ScatteredModel {
     const int lane = threadIdx.x, g = lane >> 3;
     const unsigned long long needmask = __ballot(need);
     double *const rec = (double *)((SRT_LDS unsigned long long *)lists)[LDS_SCRATCH_SLOT]; // nullptr: no staging buffer
+    SRT_AS1 f4_t *const blocks = (SRT_AS1 f4_t *)((SRT_LDS unsigned long long *)lists)[LDS_BLOCK_SLOT]; // nullptr: none
 #pragma unroll 1
     for (int j = 0; j < 64; ++j) {
       if (!((needmask >> j) & 1ull)) continue; // wave-uniform
@@ -1221,24 +1514,57 @@ struct ScatteredModel {
       double pc[3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) pc[k] = __shfl(p[k], 0);
-      // distance of this group's point from the centre; dmax: of the six offset points, e2max: of all (free point too)
-      double e2 = (g < npts) ? (p[0] - pc[0]) * (p[0] - pc[0]) + (p[1] - pc[1]) * (p[1] - pc[1]) + (p[2] - pc[2]) * (p[2] - pc[2]) : 0.0;
-      double e2s = (g < 7) ? e2 : 0.0;
-      e2 = fmax(e2, __shfl_xor(e2, 8));
-      e2 = fmax(e2, __shfl_xor(e2, 16));
-      e2 = fmax(e2, __shfl_xor(e2, 32));
+      // distance of this group's point from the centre; dmax: of the six offset points, d7: of the free point
+      const double e2own = (g < npts) ? (p[0] - pc[0]) * (p[0] - pc[0]) + (p[1] - pc[1]) * (p[1] - pc[1]) + (p[2] - pc[2]) * (p[2] - pc[2]) : 0.0;
+      double e2s = (g < 7) ? e2own : 0.0;
       e2s = fmax(e2s, __shfl_xor(e2s, 8));
       e2s = fmax(e2s, __shfl_xor(e2s, 16));
       e2s = fmax(e2s, __shfl_xor(e2s, 32));
-      const double dmax = sqrt(e2s);
-      bool shared = rec != nullptr && dmax <= 1.0e-3 * radius &&
-                    !__any(g < npts && (cx != __shfl(cx, 0) || R.cy != __shfl(R.cy, 0) || R.cz != __shfl(R.cz, 0)));
+      const double e27 = __shfl(e2own, 56); // 0 when there is no free point
+      const double dmax = sqrt(e2s), d7 = sqrt(e27), ext = fmax(dmax, d7);
+      const bool p7near = npts > 7 && d7 <= 1.0e-3 * radius;
+      const bool geom = rec != nullptr && dmax <= 1.0e-3 * radius;
+      bool shared = false;
       int n_list = 0;
-      SRT_PHASE(14);
-      if (shared) {
+      SRT_PHASE_ADD(14, (unsigned long long)d7);
+      if (geom && blocks != nullptr) {
+        // ---- from the owner's candidate block (rebuilt about this centre if the stencil has left it)
+        Block B = load_header(lists, j);
+        const double Rb = radius * (1.0 + M.bmargin), slack = 2.0e-6 * Rb;
+        const double dC = sqrt((pc[0] - B.C[0]) * (pc[0] - B.C[0]) + (pc[1] - B.C[1]) * (pc[1] - B.C[1]) + (pc[2] - B.C[2]) * (pc[2] - B.C[2]));
+        SRT_AS1 f4_t *blk = blocks + (size_t)j * BLOCK_CAP;
+        if (!(B.count >= 0 && dC + ext + slack <= M.bmargin * radius)) {
+          Rows Rc;
+          Rc.cy = __builtin_amdgcn_readlane(R.cy, 0);
+          Rc.cz = __builtin_amdgcn_readlane(R.cz, 0);
+          Rc.x0 = __builtin_amdgcn_readlane(R.x0, 0);
+          Rc.x1 = __builtin_amdgcn_readlane(R.x1, 0);
+          Rc.live = true;
+          B.count = M.build_block(pc, Rc, blk);
+#pragma unroll
+          for (int k = 0; k < 3; ++k) B.C[k] = pc[k];
+          if (lane == 0) {
+            SRT_LDS double *h = (SRT_LDS double *)lists + LDS_HDR + 4 * j;
+            h[0] = pc[0], h[1] = pc[1], h[2] = pc[2];
+            ((SRT_LDS int *)(h + 3))[0] = B.count;
+          }
+          __syncthreads(); // block == one wave: the entries written above are read by other lanes below
+          SRT_PHASE_COUNT(11);
+          SRT_PHASE(15); // (timing builds: slot 11 counts the rebuilt blocks, slot 15 their cycles; the filter's are in slot 0)
+        }
+        SRT_PHASE_ADD(12, B.count > 0 ? B.count : 0);
+        if (B.count >= 0) {
+          n_list = M.filter_block(B, pc, radius + ext + slack, blk, lists);
+          shared = true;
+          __syncthreads(); // orders the list writes before the reads below
+        }
+      }
+      if (!shared && geom &&
+          !__any(g < npts && (cx != __shfl(cx, 0) || R.cy != __shfl(R.cy, 0) || R.cz != __shfl(R.cz, 0)))) {
+        shared = true;
         // widen by the largest distance of a stencil point from the centre (plus rounding slack): a superset of
         // every point's neighbour set; each point applies its own exact test later
-        const double rs = radius + sqrt(e2);
+        const double rs = radius + ext;
         const double rs2 = rs * rs * (1.0 + 1.0e-12);
         Rows Rc;
         Rc.cy = __builtin_amdgcn_readlane(R.cy, 0);
@@ -1246,10 +1572,9 @@ struct ScatteredModel {
         Rc.x0 = __builtin_amdgcn_readlane(R.x0, 0);
         Rc.x1 = __builtin_amdgcn_readlane(R.x1, 0);
         Rc.live = true;
-        // All nine candidate rows advance together, 64 samples of each per trip: 27 coalesced loads in flight at once
-        // (one wave per SIMD: nothing else hides their latency), no index arithmetic beyond row start + lane.  List
-        // order: trip, row, lane.  The list area holds SHARED_CAP entries and a trip adds at most 9 x 64, so the
-        // overflow test (does it fit the staging buffer?) is made once per trip.
+        // All nine candidate rows advance together, 64 samples of each per trip: 27 coalesced loads in flight at once, no
+        // index arithmetic beyond row start + lane.  List order: trip, row, lane.  The list area holds SHARED_CAP entries
+        // and a trip adds at most TRIP_MAX, so the overflow test is made once per trip.
         int lo9[9], hi9[9], maxlen = 0;
 #pragma unroll
         for (int r = 0; r < 9; ++r) {
@@ -1257,7 +1582,6 @@ struct ScatteredModel {
           maxlen = max(maxlen, hi9[r] - lo9[r]);
         }
         SRT_PHASE_ADD(11, hi9[0] - lo9[0] + hi9[1] - lo9[1] + hi9[2] - lo9[2] + hi9[3] - lo9[3] + hi9[4] - lo9[4] + hi9[5] - lo9[5] + hi9[6] - lo9[6] + hi9[7] - lo9[7] + hi9[8] - lo9[8]);
-        SRT_PHASE(15);
         const SRT_AS1 double *xs = M.gxyz(), *ys = xs + M.npts, *zs = ys + M.npts;
         // (one trip ahead: the next 27 loads are in flight while this trip's samples are tested and compacted)
         int idxn[9];
@@ -1274,6 +1598,10 @@ struct ScatteredModel {
         if (maxlen > 0) fetch(0);
 #pragma unroll 1
         for (int t0 = 0; t0 < maxlen; t0 += 64) {
+          if (n_list > (SHARED_CAP < REC_CAP ? SHARED_CAP : REC_CAP) - TRIP_MAX) { // would not fit (list area, staging buffer): every group scans for itself instead
+            shared = false;
+            break;
+          }
           int idx[9];
           double qx[9], qy[9], qz[9];
 #pragma unroll
@@ -1287,25 +1615,21 @@ struct ScatteredModel {
             if (acc) lists[n_list + __popcll(m & ((1ull << lane) - 1ull))] = idx[r];
             n_list = __builtin_amdgcn_readfirstlane(n_list + __popcll(m));
           }
-          if (n_list > REC_CAP) { // does not fit: every group scans for itself instead
-            shared = false;
-            break;
-          }
         }
         __syncthreads(); // block == one wave: orders the list writes before the reads below
       }
       SRT_PHASE(0);
       SRT_PHASE_ADD(10, n_list);
-      const Fit4 fi = shared ? shared_fit<J>(p, live, livemask, npts, n_list, lists, rec, dmax) : own_fit<J>(p, live, R, lists);
+      const Fit4 fi = shared ? shared_fit<J>(p, live, livemask, npts, n_list, lists, rec, dmax, d7, p7near)
+                             : own_fit<J>(p, live, R, lists);
       SRT_PHASE(shared ? 9 : 7);
-      // hand the results to the owner through LDS (behind the lists and the staging-buffer pointer): the group leaders
+      // hand the results to the owner through LDS (behind the lists and the buffer pointers): the group leaders
       // park their four densities, the owner collects the 8 x 4
       {
-        SRT_LDS d2_t *park = (SRT_LDS d2_t *)((SRT_LDS double *)lists + LDS_SCRATCH_SLOT + 2);
+        SRT_LDS d2_t *park = (SRT_LDS d2_t *)((SRT_LDS double *)lists + LDS_PARK);
         double val[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) val[s] = (live && s < nspec) ? exp(fi.v[s]) : 0.0; // failed fit: fi = 0 -> Ns = 1
-        SRT_PHASE(12);
         if ((lane & 7) == 0) {
           park[2 * g] = d2_t{val[0], val[1]};
           park[2 * g + 1] = d2_t{val[2], val[3]};
@@ -1323,7 +1647,6 @@ struct ScatteredModel {
             }
           }
         }
-        SRT_PHASE(13);
       }
       __syncthreads(); // the lists are reused by the next owner
       SRT_PHASE(6);
@@ -1349,42 +1672,23 @@ struct ScatteredModel {
   template <int NE>
   __device__ __forceinline__ void density_stencil(const double c[3], const double d[3], const double *extra,
                                                   double (&Ns)[7 + NE][4], double *lds, bool need = true) const {
-    if (lds != nullptr) {
-      // trace / gradient / RK-step kernels: the wave serves its lanes one at a time (coop_stencil)
-      double out[32];
+    // trace / gradient / RK-step kernels: the wave serves its lanes one at a time (coop_stencil).  Those kernels always pass
+    // their LDS (USE_LDS): there is no per-lane form of the stencil here, so that they carry none of interpolate<J>()'s code
+    // and registers.
+    double out[32];
 #pragma unroll
-      for (int i = 0; i < 32; ++i) out[i] = 0.0;
-      double cc[3] = {c[0], c[1], c[2]}, dd[3] = {d[0], d[1], d[2]};
-      double ee[3] = {NE ? extra[0] : 0.0, NE ? extra[1] : 0.0, NE ? extra[2] : 0.0};
-      SRT_LDS int *lists = (SRT_LDS int *)lds;
-      if (order == 0) coop_stencil<1>(cc, dd, ee, 7 + NE, need, out, lists);
-      else if (order == 1) coop_stencil<4>(cc, dd, ee, 7 + NE, need, out, lists);
-      else if (order == 2) coop_stencil<10>(cc, dd, ee, 7 + NE, need, out, lists);
-      else coop_stencil<20>(cc, dd, ee, 7 + NE, need, out, lists);
+    for (int i = 0; i < 32; ++i) out[i] = 0.0;
+    double cc[3] = {c[0], c[1], c[2]}, dd[3] = {d[0], d[1], d[2]};
+    double ee[3] = {NE ? extra[0] : 0.0, NE ? extra[1] : 0.0, NE ? extra[2] : 0.0};
+    SRT_LDS int *lists = (SRT_LDS int *)lds;
+    if (order == 0) coop_stencil<1>(cc, dd, ee, 7 + NE, need, out, lists);
+    else if (order == 1) coop_stencil<4>(cc, dd, ee, 7 + NE, need, out, lists);
+    else if (order == 2) coop_stencil<10>(cc, dd, ee, 7 + NE, need, out, lists);
+    else coop_stencil<20>(cc, dd, ee, 7 + NE, need, out, lists);
 #pragma unroll
-      for (int i = 0; i < 7 + NE; ++i)
+    for (int i = 0; i < 7 + NE; ++i)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) Ns[i][s] = out[i * 4 + s];
-      return;
-    }
-    double p[7 + NE][3];
-#pragma unroll
-    for (int i = 0; i < 7 + NE; ++i) {
-      p[i][0] = c[0];
-      p[i][1] = c[1];
-      p[i][2] = c[2];
-    }
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      p[1 + 2 * a][a] = c[a] + d[a];
-      p[2 + 2 * a][a] = c[a] - d[a];
-    }
-    if (NE) {
-      p[7 + NE - 1][0] = extra[0];
-      p[7 + NE - 1][1] = extra[1];
-      p[7 + NE - 1][2] = extra[2];
-    }
-    density<7 + NE>(p, Ns, nullptr);
+      for (int s = 0; s < 4; ++s) Ns[i][s] = out[i * 4 + s];
   }
 
   template <int NP>
@@ -1399,14 +1703,26 @@ struct ScatteredModel {
   }
 };
 
-// The wave's slice of the launch's staging buffer (ScatteredModel::REC_CAP records per one-wave block), parked in LDS
-// behind the lists for coop_stencil; nullptr = none (every stencil then takes the own-list path).
-__device__ __forceinline__ void bind_scratch(const ScatteredModel &, double *lds, double *scratch) {
+// The wave's slices of the launch's staging buffer (ScatteredModel::REC_CAP records per one-wave block) and of its
+// candidate blocks (BLOCK_DOUBLES per one-wave block), parked in LDS behind the lists for coop_stencil; nullptr = none
+// (no staging: every stencil takes the own-list path; no blocks: every shared-path stencil scans the cells).
+__device__ __forceinline__ void bind_scratch(const ScatteredModel &, double *lds, double *scratch, double *scratch2 = nullptr) {
   if (lds == nullptr) return;
   double *mine = scratch ? scratch + (size_t)blockIdx.x * ScatteredModel::REC_CAP * ScatteredModel::REC : nullptr;
+  double *blks = scratch2 ? scratch2 + (size_t)blockIdx.x * ScatteredModel::BLOCK_DOUBLES : nullptr;
   ((SRT_LDS unsigned long long *)lds)[ScatteredModel::LDS_SCRATCH_SLOT] = (unsigned long long)mine;
+  ((SRT_LDS unsigned long long *)lds)[ScatteredModel::LDS_BLOCK_SLOT] = (unsigned long long)blks;
+  ((SRT_LDS int *)((SRT_LDS double *)lds + ScatteredModel::LDS_HDR + 4 * threadIdx.x + 3))[0] = -1;
   SRT_PHASE_ZERO((SRT_LDS double *)lds);
   __syncthreads();
 }
+__device__ __forceinline__ void new_ray_hook(const ScatteredModel &, double *lds, bool fresh) {
+  if (lds != nullptr && fresh) ((SRT_LDS int *)((SRT_LDS double *)lds + ScatteredModel::LDS_HDR + 4 * threadIdx.x + 3))[0] = -1;
+}
+template <>
+struct WaveBudget<ScatteredModel> {
+  static constexpr int LDS_DOUBLES = ScatteredModel::LDS_DOUBLES;
+  static constexpr int WAVES_PER_EU = ScatteredModel::WAVES_PER_EU;
+};
 
 } // namespace srt

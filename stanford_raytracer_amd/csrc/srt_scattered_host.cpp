@@ -113,7 +113,7 @@ bool write_points_file(const char *path, bool binary, int nspec, int64_t npts, c
   return ok;
 }
 
-bool build_scattered(const char *path, double window_scale, ScatteredHost &out, std::string &err) {
+bool build_scattered(const char *path, double window_scale, ScatteredHost &out, std::string &err, double cell_scale) {
   std::vector<double> raw;
   int nspec = 0;
   if (is_binary_points(path)) {
@@ -244,9 +244,9 @@ bool build_scattered(const char *path, double window_scale, ScatteredHost &out, 
   out.maxnearest = maxnearest;
   out.radius = maxnearest * window_scale;
   if (!(out.radius > 0)) { err = "degenerate sample set (max nearest distance is zero)"; return false; }
-  // query grid: cell edge = radius, samples sorted by cell
+  // query grid: cell edge = radius * cell_scale (>= the radius), samples sorted by cell
   Grid q;
-  build_grid(xyz, n, out.radius, lo, hi, q);
+  build_grid(xyz, n, out.radius * (cell_scale >= 1.0 ? cell_scale : 1.0), lo, hi, q);
   out.npts = n;
   out.inv_cell = q.inv;
   for (int k = 0; k < 3; ++k) {

@@ -6,7 +6,7 @@ for v in "$@"; do
   echo "== $v"; grep -a "phase cycles" gpurun_out/tim_$v.log | python -c "
 import sys
 h=[int(x) for x in sys.stdin.read().split(':')[1].split()]
-n=h[8]; names=['scan','pass1','reduce','base','pass2','solve','handoff','own','count','shared_total','n_list','cands','h_exp','h_out','s_setup','s_rows']
-print(' '.join('%s=%.0f'%(names[i],h[i]/n) for i in range(len(h)) if i!=8), 'stencils=%d'%n)"
+n=h[8]; names=['scan','pass1','reduce','base','pass2','solve','handoff','own','count','shared_total','n_list','cands_or_rebuilds','block_len','direct_calls','d7_metres','rebuild_cycles']
+print(' '.join(('%s=%.3f' if names[i] in ('cands_or_rebuilds','direct_calls') else '%s=%.0f')%(names[i],h[i]/n) for i in range(len(h)) if i!=8), 'stencils=%d'%n)"
   python -c "import sys,json; d=json.loads(open('gpurun_out/tim_$v.log').readlines()[-1]); print('kernel_ms', round(d['roofline']['kernel_ms'],1), 'steps/s %.4g' % d['value'])"
 done
