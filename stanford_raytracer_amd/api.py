@@ -131,6 +131,10 @@ def lib():
     return L
 
 
+# error codes of include/srt.h
+SRT_OK, SRT_EINVAL, SRT_EIO, SRT_EDEVICE, SRT_ENOMEM = 0, -1, -2, -3, -4
+
+
 def _check(rc):
     if rc != 0:
         raise SrtError("srt error %d: %s" % (rc, (lib().srt_last_error() or b"").decode()))

@@ -257,6 +257,10 @@ struct ScatteredModel {
   __device__ __forceinline__ static double uni(double v) {
     return __hiloint2double(uni(__double2hiint(v)), uni(__double2loint(v)));
   }
+  // the value lane `l` holds (l: compile-time constant), as a wave-uniform number: v_readlane, no LDS round trip
+  __device__ __forceinline__ static double from_lane(double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+  }
   template <class T>
   __device__ __forceinline__ static T *uni(T *v) {
     const unsigned long long a = (unsigned long long)v;
@@ -685,18 +689,22 @@ struct ScatteredModel {
     return flushed;
   }
 
-  // dposv 'U' on the packed upper triangle (row a holds A[a][a..J-1]) with right-hand side e_1: A = U^T U, U^T z = e_1, U y = z
+  // dposv 'U' on the packed upper triangle (row a holds A[a][a..J-1]) with right-hand side e_1: A = U^T U, U^T z = e_1, U y = z.
+  // The reciprocals of the pivots are kept: the two substitutions multiply by them where dtrsv divides (<= 1 ulp per entry,
+  // against a summation order that differs from the reference's anyway) -- 2 J divisions less on one dependent chain.
   template <int J>
   __device__ __forceinline__ static int chol_y(double (&A)[J * (J + 1) / 2], double (&y)[J]) {
     auto at = [&](int r, int c) -> double & { return A[r * J - r * (r - 1) / 2 + (c - r)]; };
+    double rinv[J];
 #pragma unroll
     for (int j = 0; j < J; ++j) {
       double s = at(j, j);
 #pragma unroll
       for (int l = 0; l < j; ++l) s -= at(l, j) * at(l, j);
       if (!(s > 0.0)) return 1;
-      double ujj = sqrt(s), inv = 1.0 / ujj;
+      const double ujj = sqrt(s), inv = fdiv(1.0, ujj);
       at(j, j) = ujj;
+      rinv[j] = inv;
 #pragma unroll
       for (int c = j + 1; c < J; ++c) {
         double t = at(j, c);
@@ -710,14 +718,14 @@ struct ScatteredModel {
       double t = (i == 0) ? 1.0 : 0.0;
 #pragma unroll
       for (int l = 0; l < i; ++l) t -= at(l, i) * y[l];
-      y[i] = t / at(i, i);
+      y[i] = t * rinv[i];
     }
 #pragma unroll
     for (int i = J - 1; i >= 0; --i) { // U y = z
       double t = y[i];
 #pragma unroll
       for (int l = i + 1; l < J; ++l) t -= at(i, l) * y[l];
-      y[i] = t / at(i, i);
+      y[i] = t * rinv[i];
     }
     return 0;
   }
@@ -811,9 +819,25 @@ struct ScatteredModel {
   }
   static_assert(sizeof(Pass1Out) <= 32 * 8, "Pass1Out must fit the park area");
 
+  // What the weights need of a sample -- {x, y}, {z, r_c}, {cos a_c, sin a_c} -- waits for them in the list area's free part
+  // behind the list (three arrays of `cap` 16-byte entries) instead of coming back from device memory; samples beyond
+  // the capacity are read back from their records.
+  struct Side {
+    SRT_LDS d2_t *a, *b, *c;
+    int cap;
+  };
+  __device__ __forceinline__ static Side side_of(SRT_LDS const int *list, int n_list) {
+    const int used = (n_list + 3) >> 2; // 16-byte units the list occupies
+    Side S;
+    S.cap = (LIST_DOUBLES / 2 - used) / 3;
+    S.a = (SRT_LDS d2_t *)const_cast<SRT_LDS int *>(list) + used;
+    S.b = S.a + S.cap;
+    S.c = S.b + S.cap;
+    return S;
+  }
   // p7near: the free point 7 lies as close to the centre as the six offset points may (<= 1e-3 radius) and takes the
   // addition theorem / the series like them; else its window is evaluated by cos() and its weight by etainv().
-  __device__ __noinline__ void sf_pass1(const double (&p_in)[3], unsigned long long livemask, int npts, int n_list,
+  __device__ __forceinline__ void sf_pass1(const double (&p_in)[3], unsigned long long livemask, int npts, int n_list,
                                         SRT_LDS const int *list, double *rec_flat, bool p7near) const {
     const ScatteredModel M = uniform_copy();
     const double p[3] = {p_in[0], p_in[1], p_in[2]};
@@ -826,7 +850,7 @@ struct ScatteredModel {
 #pragma unroll
     for (int gg = 0; gg < 8; ++gg)
 #pragma unroll
-      for (int k = 0; k < 3; ++k) pg[gg][k] = uni(__shfl(p[k], 8 * gg));
+      for (int k = 0; k < 3; ++k) pg[gg][k] = from_lane(p[k], 8 * gg);
     SRT_PHASE_BEGIN(list);
     double s8[8], v8[8];
     int c8[8];
@@ -838,6 +862,7 @@ struct ScatteredModel {
     bool lv8[8];
 #pragma unroll
     for (int gg = 0; gg < 8; ++gg) lv8[gg] = (livemask >> (8 * gg)) & 1ull; // wave-uniform
+    const Side side = side_of(list, n_list);
     // (one sample ahead: the next gather is in flight while this sample is worked on)
     d2_t na = {0.0, 0.0}, nb = na, nc = na, nd = na;
     if (lane < n_list) {
@@ -893,8 +918,14 @@ struct ScatteredModel {
       r[1] = qb;
       r[2] = qc;
       r[3] = d2_t{qd.x, 0.0};
-      r[4] = d2_t{rc, 0.0};
-      r[5] = d2_t{ca, sa};
+      if (k < side.cap) { // what the weights need waits in LDS ..
+        side.a[k] = qa;
+        side.b[k] = d2_t{q2, rc};
+        side.c[k] = d2_t{ca, sa};
+      } else { // .. or, for a list longer than the side arrays, in the record
+        r[4] = d2_t{rc, 0.0};
+        r[5] = d2_t{ca, sa};
+      }
     }
     SRT_PHASE(1);
     SRT_LDS Pass1Out *o = pass1_out(list);
@@ -913,7 +944,7 @@ struct ScatteredModel {
 
   // All eight half-weights of every sample of the list (see above); usemask: the reference's weight > 1e-16 mask (:316-317)
   template <int J>
-  __device__ __noinline__ void sf_weights(const double (&p_in)[3], bool live, unsigned long long livemask, int npts, int n_list,
+  __device__ __forceinline__ void sf_weights(const double (&p_in)[3], bool live, unsigned long long livemask, int npts, int n_list,
                                           SRT_LDS const int *list, double *rec_flat, double dmax6, double d7, bool p7near,
                                           bool usemask) const {
     const ScatteredModel M = uniform_copy();
@@ -932,37 +963,35 @@ struct ScatteredModel {
       lv8[gg] = (livemask >> (8 * gg)) & 1ull;
       fit8[gg] = lv8[gg] && gg < npts && uni(o->cnt8[gg]) >= J;
 #pragma unroll
-      for (int k = 0; k < 3; ++k) pg[gg][k] = uni(__shfl(p[k], 8 * gg));
+      for (int k = 0; k < 3; ++k) pg[gg][k] = from_lane(p[k], 8 * gg);
     }
     // the centre's h against each point's: eta_g = h_c / h_g - 1
     double eta8[8], etamax6 = 0.0;
 #pragma unroll
     for (int gg = 0; gg < 8; ++gg) {
-      eta8[gg] = (hin8[0] - hin8[gg]) / hin8[gg];
+      eta8[gg] = fdiv(hin8[0] - hin8[gg], hin8[gg]);
       if (gg < 7 && fit8[gg]) etamax6 = fmax(etamax6, fabs(eta8[gg]));
     }
     const double eta7 = fit8[7] ? fabs(eta8[7]) : 0.0;
     const bool base_ok = M.exact != 1 && uni(o->cnt8[0]) >= 1 && hin8[0] > 0.0 && etamax6 <= 1.0e-3;
-    const double sh = base_ok ? exp(-1.1 * log(hin8[0] / 4.0)) : 0.0; // (h_c / 4)**-1.1: u_c = a sh
+    const double sh = base_ok ? fm::exp_any(-1.1 * fm::log_pos(hin8[0] * 0.25)) : 0.0; // (h_c / 4)**-1.1: u_c = a sh
     // the points' offsets from the centre: point 1 + 2a / 2 + 2a = centre +- da e_a, point 7 = centre + (o7x, o7y, o7z)
     const double da3[3] = {pg[1][0] - pg[0][0], pg[3][1] - pg[0][1], pg[5][2] - pg[0][2]};
     const double mda3[3] = {pg[2][0] - pg[0][0], pg[4][1] - pg[0][1], pg[6][2] - pg[0][2]};
     const double o7[3] = {pg[7][0] - pg[0][0], pg[7][1] - pg[0][1], pg[7][2] - pg[0][2]};
     const double o7sq = o7[0] * o7[0] + o7[1] * o7[1] + o7[2] * o7[2];
-    // (one record ahead)
-    d2_t n0 = {0.0, 0.0}, n1 = n0, n4 = n0, n5 = n0;
-    if (lane < n_list) {
-      const SRT_AS1 d2_t *r = (const SRT_AS1 d2_t *)(rec + (size_t)lane * REC);
-      n0 = r[0], n1 = r[1], n4 = r[4], n5 = r[5];
-    }
+    const Side side = side_of(list, n_list);
 #pragma unroll 1
     for (int k = lane; k < n_list; k += 64) {
-      const d2_t c0 = n0, c1 = n1, c4 = n4, c5 = n5;
-      if (k + 64 < n_list) {
-        const SRT_AS1 d2_t *r = (const SRT_AS1 d2_t *)(rec + (size_t)(k + 64) * REC);
-        n0 = r[0], n1 = r[1], n4 = r[4], n5 = r[5];
+      d2_t s0, s1, s2;
+      if (k < side.cap) {
+        s0 = side.a[k], s1 = side.b[k], s2 = side.c[k];
+      } else { // (a list longer than the side arrays: back from the record)
+        const SRT_AS1 d2_t *r = (const SRT_AS1 d2_t *)(rec + (size_t)k * REC);
+        const d2_t c1 = r[1], c4 = r[4];
+        s0 = r[0], s1 = d2_t{c1.x, c4.x}, s2 = r[5];
       }
-      const double q0 = c0.x, q1 = c0.y, q2 = c1.x, rc = c4.x, ca = c5.x, sa = c5.y;
+      const double q0 = s0.x, q1 = s0.y, q2 = s1.x, rc = s1.y, ca = s2.x, sa = s2.y;
       const double dc[3] = {q0 - pg[0][0], q1 - pg[0][1], q2 - pg[0][2]};
       const double ssc = dc[0] * dc[0] + dc[1] * dc[1] + dc[2] * dc[2];
       const double xr = rc + reps;
@@ -1125,26 +1154,44 @@ struct ScatteredModel {
         else InterpModel::wait_vm<0>();
         if (fit) {
           const unsigned cbase = ring0 + (unsigned)((c % NBUF) * 8192);
-#pragma unroll 1
-          for (int i = 0; i < 8; ++i) {
-            const int k = c * 64 + 8 * i + sub;
+          // (one record ahead, two register sets in turn: a record's LDS reads are in flight while the previous one is folded
+          // in; inline asm: the compiler's wait-count pass would make an LDS load it can see wait for ALL DMA in flight)
+          struct RecRegs {
+            d2_t c0, c1, c2;
+            double ln3, w2;
+          };
+          auto rd = [&](RecRegs &R, int i) {
             const unsigned ra = cbase + (unsigned)(i * 128);
-            d2_t c0, c1, c2, c3;
-            double w2;
-            // (inline asm: the compiler's wait-count pass would make an LDS load it can see wait for ALL DMA in flight)
             asm volatile("ds_read_b128 %0, %5\n\t"
                          "ds_read_b128 %1, %5 offset:1024\n\t"
                          "ds_read_b128 %2, %5 offset:2048\n\t"
                          "ds_read_b64 %3, %5 offset:3072\n\t"
-                         "ds_read_b64 %4, %6\n\t"
-                         "s_waitcnt lgkmcnt(0)"
-                         : "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(c3.x), "=&v"(w2)
+                         "ds_read_b64 %4, %6"
+                         : "=&v"(R.c0), "=&v"(R.c1), "=&v"(R.c2), "=&v"(R.ln3), "=&v"(R.w2)
                          : "v"(ra), "v"(ra + slot_off)
                          : "memory");
-            w2 = k < n_list ? w2 : 0.0;
+          };
+          auto landed = [&](RecRegs &R) {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(R.c0), "+v"(R.c1), "+v"(R.c2), "+v"(R.ln3), "+v"(R.w2) : : "memory");
+          };
+          auto use = [&](const RecRegs &R, int i) {
+            const int k = c * 64 + 8 * i + sub;
+            const double w2 = k < n_list ? R.w2 : 0.0;
             kept += w2 != 0.0 ? 1 : 0;
-            const double ln[4] = {c1.y, c2.x, c2.y, c3.x};
-            fold(w2, c0.x - p[0], c0.y - p[1], c1.x - p[2], ln);
+            const double ln[4] = {R.c1.y, R.c2.x, R.c2.y, R.ln3};
+            fold(w2, R.c0.x - p[0], R.c0.y - p[1], R.c1.x - p[2], ln);
+          };
+          RecRegs Ra, Rb;
+          rd(Ra, 0);
+          landed(Ra);
+#pragma unroll 1
+          for (int i = 0; i < 8; i += 2) {
+            rd(Rb, i + 1);
+            use(Ra, i);
+            landed(Rb);
+            rd(Ra, i + 2 < 8 ? i + 2 : 7); // (the last one is read for nothing)
+            use(Rb, i + 1);
+            landed(Ra);
           }
         }
       }
@@ -1207,19 +1254,29 @@ struct ScatteredModel {
     return fi;
   }
 
+  // pass 1 + weights in one out-of-line body (one call, one set of registers saved around it); returns whether this group's
+  // fit exists: its point has at least J samples (else status 2: too few samples, lsinterp_mod.f95:262-264)
+  template <int J>
+  __device__ __noinline__ bool sf_prepare(const double (&p)[3], bool live, unsigned long long livemask, int npts, int n_list,
+                                          SRT_LDS const int *list, double *rec, double dmax6, double d7, bool p7near) const {
+    sf_pass1(p, livemask, npts, n_list, list, rec, p7near);
+    sf_weights<J>(p, live, livemask, npts, n_list, list, rec, dmax6, d7, p7near, true);
+    return live && pass1_out(list)->cnt8[threadIdx.x >> 3] >= J;
+  }
+  template <int J>
+  __device__ __noinline__ void sf_reweigh(const double (&p)[3], bool live, unsigned long long livemask, int npts, int n_list,
+                                          SRT_LDS const int *list, double *rec, double dmax6, double d7, bool p7near) const {
+    sf_weights<J>(p, live, livemask, npts, n_list, list, rec, dmax6, d7, p7near, false);
+  }
   template <int J>
   __device__ __forceinline__ Fit4 shared_fit(const double (&p)[3], bool live, unsigned long long livemask, int npts, int n_list,
                                              SRT_LDS const int *list, double *rec, double dmax6, double d7, bool p7near) const {
-    const int g = threadIdx.x >> 3;
-    sf_pass1(p, livemask, npts, n_list, list, rec, p7near);
-    // this group's fit exists iff its point has at least J samples (else status 2: too few samples, lsinterp_mod.f95:262-264)
-    const bool fit = live && pass1_out(list)->cnt8[g] >= J;
-    sf_weights<J>(p, live, livemask, npts, n_list, list, rec, dmax6, d7, p7near, true);
+    const bool fit = sf_prepare<J>(p, live, livemask, npts, n_list, list, rec, dmax6, d7, p7near);
     int kept = 0;
     Fit4 fi = sf_sums<J>(p, fit, n_list, list, rec, kept);
     const bool again = fit && kept < J; // threw out too many samples: use them all (:319-323)
     if (__any(again)) {                 // (wave-uniform; rare)
-      sf_weights<J>(p, live, livemask, npts, n_list, list, rec, dmax6, d7, p7near, false);
+      sf_reweigh<J>(p, live, livemask, npts, n_list, list, rec, dmax6, d7, p7near);
       const Fit4 f2 = sf_sums<J>(p, again, n_list, list, rec, kept);
       if (again) fi = f2;
     }

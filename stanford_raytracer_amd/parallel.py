@@ -51,20 +51,31 @@ def pack_rows_torch(rows, nrows, outputper):
     return packed.contiguous(), offsets
 
 
-def pack_rows_device(rows, nrows, outputper, stream=None):
-    """srt_pack_rows_device on torch CUDA tensors -> (packed[total,20] (a view of a worst-case buffer), offsets[n+1])."""
+_PACK_BUFFERS = {}  # (device, rows capacity, slot) -> worst-case packed buffer, reused from step to step
+
+
+def pack_rows_device(rows, nrows, outputper, stream=None, slot=0):
+    """srt_pack_rows_device on torch CUDA tensors -> (packed[n * slots, 20], offsets[n + 1]).  `packed` is a worst-case
+    buffer that is allocated once per (device, size, slot) and reused; its valid rows are the first offsets[n] -- a number
+    that stays ON THE DEVICE: nothing here waits for the GPU (the gather reads it together with the other ranks' counts).
+    `slot` separates the buffers of steps that are in flight together (trace_sharded_pipelined)."""
     import torch
 
     from . import api
 
     n, slots = rows.shape[0], rows.shape[1]
+    cap = max(n * slots, 1)
+    key = (rows.device, cap, slot)
+    packed = _PACK_BUFFERS.get(key)
+    if packed is None:
+        for k in [k for k in _PACK_BUFFERS if k[0] == rows.device and k[2] == slot]:
+            del _PACK_BUFFERS[k]  # (a launch set of another size on this device: one buffer per slot is kept)
+        packed = _PACK_BUFFERS[key] = torch.empty((cap, ROW), dtype=torch.float64, device=rows.device)
     offsets = torch.empty(n + 1, dtype=torch.int64, device=rows.device)
-    packed = torch.empty((max(n * slots, 1), ROW), dtype=torch.float64, device=rows.device)
     st = stream if stream is not None else torch.cuda.current_stream(rows.device)
     api._check(api.lib().srt_pack_rows_device(slots, outputper, n, rows.data_ptr(), nrows.data_ptr(), offsets.data_ptr(),
                                               packed.data_ptr(), n * slots, st.cuda_stream))
-    total = int(offsets[n].item())  # synchronises the stream
-    return packed[:total], offsets
+    return packed, offsets
 
 
 def _sync(t):
@@ -74,10 +85,12 @@ def _sync(t):
         torch.cuda.synchronize(t.device)
 
 
-def gather_packed(dist, packed, nrows, stop, nrays, dst=0):
+def gather_packed(dist, packed, nrows, stop, nrays, dst=0, total=None):
     """Variable-length gather to `dst`: every rank contributes packed[total_r,20], nrows[n_r], stop[n_r] of its
-    contiguous shard.  Returns (packed_all[total,20], nrows_all[nrays], stop_all[nrays], bytes_received) on dst, None
-    elsewhere.  gloo cannot move device memory: there the buffers are staged through the host."""
+    contiguous shard.  `total` (optional): one-element int64 tensor on packed's device holding the number of valid rows of
+    `packed` (a worst-case buffer, pack_rows_device); None = all of packed.  The counts exchange is the one place where
+    the host waits for the device.  Returns (packed_all[total,20], nrows_all[nrays], stop_all[nrays], bytes_received) on
+    dst, None elsewhere.  gloo cannot move device memory: there the buffers are staged through the host."""
     import torch
 
     world, rank = dist.get_world_size(), dist.get_rank()
@@ -85,13 +98,19 @@ def gather_packed(dist, packed, nrows, stop, nrays, dst=0):
     stage = dist.get_backend() == "gloo" and packed.is_cuda
     cdev = torch.device("cpu") if stage else dev
     # 1. counts: [rays, kept rows] of every rank
-    mine = torch.tensor([nrows.shape[0], packed.shape[0]], dtype=torch.int64, device=cdev)
+    if total is None:
+        mine = torch.tensor([nrows.shape[0], packed.shape[0]], dtype=torch.int64, device=cdev)
+    else:
+        mine = torch.cat([torch.tensor([nrows.shape[0]], dtype=torch.int64, device=dev), total.reshape(1).to(torch.int64)]).to(cdev)
     allc = [torch.zeros(2, dtype=torch.int64, device=cdev) for _ in range(world)]
     dist.all_gather(allc, mine)
-    counts = torch.stack(allc).cpu().numpy()
+    counts = torch.stack(allc).cpu().numpy()  # (the host waits here: the sizes of the transfers below)
     nray_r, nrow_r = counts[:, 0], counts[:, 1]
     if int(nray_r.sum()) != nrays:
         raise RuntimeError("shards cover %d rays, expected %d" % (int(nray_r.sum()), nrays))
+    if int(nrow_r[rank]) > packed.shape[0]:
+        raise RuntimeError("rank %d: %d packed rows reported, the buffer holds %d" % (rank, int(nrow_r[rank]), packed.shape[0]))
+    packed = packed[:int(nrow_r[rank])]
     ray0 = np.concatenate([[0], np.cumsum(nray_r)])
     row0 = np.concatenate([[0], np.cumsum(nrow_r)])
     src = [t.cpu() if stage else t for t in (packed.contiguous(), nrows.contiguous(), stop.contiguous())]
@@ -131,16 +150,68 @@ def trace_sharded(dist, nrays, trace_fn, pack_fn, dst=0, timings=None):
     rows, nrows, stop = trace_fn(lo, hi)
     _sync(rows)
     t1 = time.perf_counter()
-    packed, _ = pack_fn(rows, nrows)
+    packed, offsets = pack_fn(rows, nrows)
     _sync(packed)
     t2 = time.perf_counter()
-    res = gather_packed(dist, packed, nrows, stop, nrays, dst)
+    res = gather_packed(dist, packed, nrows, stop, nrays, dst, total=offsets[-1:])
     _sync(packed)
     t3 = time.perf_counter()
     if timings is not None:
         timings.update(trace_s=t1 - t0, pack_s=t2 - t1, gather_s=t3 - t2, gather_bytes=res[3] if res is not None else 0,
                        shard=(lo, hi))
     return None if res is None else res[:3]
+
+
+def trace_sharded_pipelined(dist, nrays, steps, launch_fn, pack_fn, dst=0, keep_last_only=True):
+    """`steps` steps of trace -> pack -> gather with the pack + gather of step k overlapped with the trace of step k + 1:
+    launch_fn(k) enqueues the trace of this rank's shard on the CURRENT stream into output buffer set k % 2 and returns
+    (rows, nrows, stop); the pack and the gather of step k run on a side stream that waits for that trace only, while the
+    current stream already carries the trace of step k + 1.  (The persistent trace kernel takes every CU's registers, so
+    the pack / RCCL kernels of step k get onto the chip as the waves of step k + 1 thin out: what is hidden is the
+    gather behind the next launch's tail.)  pack_fn(rows, nrows, slot) -> (packed, offsets).  CPU tensors (gloo tests):
+    the same order of operations without streams.  Returns the gathered (packed, nrows, stop) of the last step on dst
+    (of every step if keep_last_only is False), None elsewhere."""
+    import torch
+
+    results, pending = [], None
+    cuda = None
+    side = None
+
+    def finish(item):
+        k, rows, nrows, stop, ev = item
+        if cuda:
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                packed, offsets = pack_fn(rows, nrows, k % 2)
+                res = gather_packed(dist, packed, nrows, stop, nrays, dst, total=offsets[-1:])
+        else:
+            packed, offsets = pack_fn(rows, nrows, k % 2)
+            res = gather_packed(dist, packed, nrows, stop, nrays, dst, total=offsets[-1:])
+        if res is not None:
+            if keep_last_only:
+                results.clear()
+            results.append(res[:3])
+
+    for k in range(steps):
+        rows, nrows, stop = launch_fn(k)
+        if cuda is None:
+            cuda = rows.is_cuda
+            if cuda:
+                side = torch.cuda.Stream(rows.device)
+        ev = None
+        if cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(rows.device))
+        if pending is not None:
+            finish(pending)  # (the host waits inside for the counts of step k - 1 while the device traces step k)
+        pending = (k, rows, nrows, stop, ev)
+    if pending is not None:
+        finish(pending)
+    if cuda:
+        torch.cuda.current_stream().wait_stream(side)
+    if not results:
+        return None
+    return results[-1] if keep_last_only else results
 
 
 def unpack_rows(packed, nrows, outputper, slots):

@@ -93,3 +93,42 @@ def test_gather_world2_gloo():
             p.join(120)
             assert p.exitcode == 0
         assert q.get(timeout=10) is True
+
+
+def _worker_pipelined(rank, world, port, nrays, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = parallel.shard_bounds(nrays, rank, world)
+
+    def launch(k):  # step k produces different rows (k added), so a mixed-up step would show
+        rows, nrows, stop = _fake_trace(lo, hi)
+        return rows + 1000.0 * k, nrows, stop
+
+    outs = parallel.trace_sharded_pipelined(dist, nrays, 3, launch, lambda rows, nrows, slot: _pack(rows, nrows), dst=0,
+                                            keep_last_only=False)
+    if rank == 0:
+        er, en, es = _fake_trace(0, nrays)
+        ok = len(outs) == 3
+        for k, (packed, nrows, stop) in enumerate(outs):
+            ep, _ = _pack(er + 1000.0 * k, en)
+            ok = ok and bool(torch.equal(packed, ep) and torch.equal(nrows, en) and torch.equal(stop, es))
+        q.put(ok)
+    else:
+        assert outs is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_pipelined_gather_world2_gloo():
+    """trace_sharded_pipelined (gather of step k behind the trace of step k + 1): every step's rows arrive, in step order."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_pipelined, args=(r, 2, port, 11, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=10) is True

@@ -82,7 +82,9 @@ def test_two_rank_gather_is_bit_identical_to_one_rank():
     model, p, batch = _setup(0, NRAYS)
     rows, nrows, stop = batch.trace()
     torch.cuda.synchronize()
-    packed1, off = parallel.pack_rows_device(rows, nrows, OUTPUTPER)
+    buf, off = parallel.pack_rows_device(rows, nrows, OUTPUTPER)
+    assert buf.shape[0] == NRAYS * batch.slots  # the reused worst-case buffer; its valid rows are the first off[-1]
+    packed1 = buf[:int(off[-1])]
     pt, offt = parallel.pack_rows_torch(rows, nrows, OUTPUTPER)  # the HIP packer against the plain-torch one
     assert torch.equal(off, offt) and torch.equal(packed1, pt)
     assert np.array_equal(nrows2, nrows.cpu().numpy()) and np.array_equal(stop2, stop.cpu().numpy())
@@ -110,10 +112,14 @@ def test_pack_rows_edge_cases():
     packed, off = parallel.pack_rows_device(rows, nrows, per)
     assert off.cpu().tolist() == [0, 0, 1, 2, 4, 9, 14, 19]
     pt, offt = parallel.pack_rows_torch(rows, nrows, per)
-    assert torch.equal(off, offt) and torch.equal(packed, pt)
+    assert torch.equal(off, offt) and torch.equal(packed[:19], pt)
+    again, _ = parallel.pack_rows_device(rows, nrows, per)
+    assert again.data_ptr() == packed.data_ptr()  # one buffer per (device, size, slot), reused from step to step
+    other, _ = parallel.pack_rows_device(rows, nrows, per, slot=1)
+    assert other.data_ptr() != packed.data_ptr() and torch.equal(other[:19], pt)
     e = torch.zeros((0, slots, 20), dtype=torch.float64, device=dev)
     packed, off = parallel.pack_rows_device(e, torch.zeros(0, dtype=torch.int32, device=dev), per)
-    assert packed.shape[0] == 0 and off.cpu().tolist() == [0]
+    assert off.cpu().tolist() == [0]
     # capacity 3 rows: rays 0..2 fit, the total still reports 19
     offs = torch.empty(8, dtype=torch.int64, device=dev)
     small = torch.full((3, 20), -1.0, dtype=torch.float64, device=dev)
@@ -121,3 +127,85 @@ def test_pack_rows_edge_cases():
                                               small.data_ptr(), 3, None))
     torch.cuda.synchronize()
     assert int(offs[7]) == 19 and torch.equal(small[:2], pt[:2]) and float(small[2, 0]) == -1.0
+
+
+def test_pack_rows_rejects_host_pointers_and_keeps_the_callers_device():
+    """srt_pack_rows_device works on the device that OWNS the buffers, whatever device the calling thread is bound to, and
+    leaves that binding alone; pointers that are not device memory are refused (round-2 advice)."""
+    import torch
+
+    from stanford_raytracer_amd import api
+
+    api.init(0)
+    dev = torch.device("cuda", 0)
+    slots, per = 2, 1
+    nrows = torch.tensor([1, 2], dtype=torch.int32, device=dev)
+    rows = torch.ones((2, slots, 20), dtype=torch.float64, device=dev)
+    offs = torch.empty(3, dtype=torch.int64, device=dev)
+    out = torch.empty((4, 20), dtype=torch.float64, device=dev)
+    before = torch.cuda.current_device()
+    api._check(api.lib().srt_pack_rows_device(slots, per, 2, rows.data_ptr(), nrows.data_ptr(), offs.data_ptr(), out.data_ptr(), 4, None))
+    torch.cuda.synchronize()
+    assert offs.cpu().tolist() == [0, 1, 3] and torch.cuda.current_device() == before
+    host = torch.empty(3, dtype=torch.int64)  # a host buffer where device memory is required
+    rc = api.lib().srt_pack_rows_device(slots, per, 2, rows.data_ptr(), nrows.data_ptr(), host.data_ptr(), out.data_ptr(), 4, None)
+    assert rc == api.SRT_EINVAL and b"not device memory" in api.lib().srt_last_error()
+
+
+def _nccl_world1(port, q, pipelined):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+
+    from stanford_raytracer_amd import parallel
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    assert dist.get_backend() == "nccl"
+    model, p, batch = _setup(0, NRAYS)
+    if pipelined:
+        from stanford_raytracer_amd.device_batch import DeviceBatch
+        from stanford_raytracer_amd import workloads as wl
+
+        pos0, dir0, w0 = wl.launch_set(NRAYS, 4)
+        batch = DeviceBatch(model, p, pos0, dir0, w0, torch.device("cuda", 0), nbuf=2)
+        out = parallel.trace_sharded_pipelined(dist, NRAYS, 3, lambda k: batch.trace(k % 2),
+                                               lambda rows, nrows, slot: parallel.pack_rows_device(rows, nrows, OUTPUTPER, slot=slot))
+        tm = {"gather_bytes": 0}
+    else:
+        tm = {}
+        out = parallel.trace_sharded(dist, NRAYS, lambda a, b: batch.trace(),
+                                     lambda rows, nrows: parallel.pack_rows_device(rows, nrows, OUTPUTPER), dst=0, timings=tm)
+    packed, nrows, stop = out
+    assert packed.is_cuda and nrows.is_cuda  # the device-tensor branch: nothing was staged through the host
+    q.put((packed.cpu().numpy(), nrows.cpu().numpy(), stop.cpu().numpy(), tm["gather_bytes"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("pipelined", [False, True])
+def test_rccl_branch_world_size_one(pipelined):
+    """Backend "nccl" (= RCCL) with ONE rank: parallel.trace_sharded / trace_sharded_pipelined end to end through the branch
+    an 8-GPU run takes -- counts all_gather on device int64 tensors, device-resident packed rows, no host staging -- before
+    any multi-GPU run exists (RCCL refuses two ranks on one device, so the 2-rank test above has to use gloo)."""
+    import torch
+    import torch.multiprocessing as mp
+
+    from stanford_raytracer_amd import parallel
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    pr = ctx.Process(target=_nccl_world1, args=(_free_port(), q, pipelined))
+    pr.start()
+    packed2, nrows2, stop2, nbytes = q.get(timeout=300)
+    pr.join(120)
+    assert pr.exitcode == 0
+    model, p, batch = _setup(0, NRAYS)
+    rows, nrows, stop = batch.trace()
+    torch.cuda.synchronize()
+    pt, off = parallel.pack_rows_torch(rows, nrows, OUTPUTPER)
+    assert nbytes == 0  # nothing travels to the only rank
+    assert np.array_equal(nrows2, nrows.cpu().numpy()) and np.array_equal(stop2, stop.cpu().numpy())
+    assert np.array_equal(packed2.view(np.uint64), pt.cpu().numpy().view(np.uint64))
