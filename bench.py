@@ -14,6 +14,7 @@ Workloads (BASELINE.json configs; --workload):
   interp4m             config[3]: 4M rays (seed 4) sharded over the N ranks, strong scaling, gather timed apart.
   ngo100k              config[1]: 100k rays, Ngo model, adaptive RK45, maxsteps=512, outputper=8 (compute-bound).
   scattered825k        config[4]: 1M rays, scattered model on the 825k-sample set, maxsteps=64, outputper=8.
+  interp_igrf200k / interp_t04_64k   config[2]'s set and grid with --use_igrf=1 / --use_tsyganenko=1 (200k / 64k rays).
 The default invocation additionally times one short run of the other configs (`other_configs`), so that every
 BASELINE config is driver-timed.  Inputs are synthetic (seeded launch set + analytic plasmasphere)
 and resident in HBM before the timed region starts.
@@ -56,7 +57,15 @@ WORKLOADS = {
     "interp4m": dict(kind="interp", rays=4_000_000, seed=4, scaling="strong", maxsteps=256, outputper=16, del_=1e-6),
     "ngo100k": dict(kind="ngo", rays=100_000, seed=2, scaling="weak", maxsteps=512, outputper=8, del_=1e-4),
     "scattered825k": dict(kind="scattered", rays=1_000_000, seed=5, scaling="weak", maxsteps=64, outputper=8, del_=1e-6),
+    # config[2]'s launch set and grid with the reference's field options (short launches: the field tails cost
+    # 4 x / 100 x the dipole kernel's time)
+    "interp_igrf200k": dict(kind="interp", rays=200_000, seed=3, scaling="weak", maxsteps=256, outputper=16, del_=1e-6, field=(1, 0)),
+    "interp_t04_64k": dict(kind="interp", rays=65_536, seed=3, scaling="weak", maxsteps=256, outputper=16, del_=1e-6, field=(0, 1)),
 }
+FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector peak
+VALU_MIX_COUNTERS = ["SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_FMA_F32",
+                     "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_ADD_F32", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES"]
+T04_PARMOD = [4.0, -30.0, 1.0, -5.0, 0.132, 0.303, 0.083, 0.07, 0.211, 0.308]  # Pdyn, Dst, ByIMF, BzIMF, W1..W6
 
 
 def parse_args(argv=None):
@@ -217,6 +226,7 @@ class Ctx:
     def __init__(self, args, torch, dev, dist, rank, world):
         self.args, self.torch, self.dev, self.dist, self.rank, self.world = args, torch, dev, dist, rank, world
         self.models = {}
+        self.field = {}  # id(model) -> (use_igrf, use_tsyganenko) currently set on it
         self.tmp = tempfile.mkdtemp(prefix="srt_bench_")
 
 
@@ -247,12 +257,13 @@ def make_model(ctx, kind, grid_n, npts):
         with open(cfg, "w") as f:
             f.write(wl.NEWRAY_PLASMAPAUSE)
         model = api.Model.ngo(cfg)
-    a = ctx.args
-    if a.use_igrf or a.use_tsyganenko:
-        model.set_field(use_igrf=a.use_igrf, use_tsyganenko=a.use_tsyganenko,
-                        parmod=[4.0, -30.0, 1.0, -5.0, 0.132, 0.303, 0.083, 0.07, 0.211, 0.308])
     ctx.models[key] = (model, extra)
     return model, extra, time.time() - t0
+
+
+def field_of(args, W):
+    """(use_igrf, use_tsyganenko) of a workload: its own, else the command line's."""
+    return W.get("field", (args.use_igrf, args.use_tsyganenko))
 
 
 def run_workload(ctx, name, steps, warmup, rays_override=0, nstream=1, keep=False):
@@ -272,6 +283,10 @@ def run_workload(ctx, name, steps, warmup, rays_override=0, nstream=1, keep=Fals
                         maxsteps=args.maxsteps or W["maxsteps"], outputper=W["outputper"], del_=W["del_"],
                         refill_threshold=args.refill, ray_order=args.ray_order)
     model, extra, setup_s = make_model(ctx, kind, grid_n, npts)
+    fld = field_of(args, W)
+    if fld != ctx.field.get(id(model), (0, 0)):  # (the models are cached across workloads: the option is a switch on the handle)
+        model.set_field(use_igrf=fld[0], use_tsyganenko=fld[1], parmod=T04_PARMOD if fld[1] else None)
+        ctx.field[id(model)] = fld
     # ONE launch set for the whole job, cut into contiguous shards (ceil(n/world) rays per rank)
     pos0, dir0, w0 = wl.launch_set(total, W["seed"])
     lo, hi = parallel.shard_bounds(total, rank, world)
@@ -338,11 +353,79 @@ def run_workload(ctx, name, steps, warmup, rays_override=0, nstream=1, keep=Fals
         "accepted": int(tot[0]), "attempts": int(tot[1]), "wave_attempts": int(tot[2]),
         "value": float(tot[0]) / max(float(red[0]), 1e-12), "setup_s": setup_s, "nstream": nstream, "gather": gather,
         "stop": o["stop"].cpu().numpy(), "nrows": o["nrows"].cpu().numpy(),
-        "launch": (pos0[lo:hi], dir0[lo:hi], w0[lo:hi]),
+        "launch": (pos0[lo:hi], dir0[lo:hi], w0[lo:hi]), "field": fld,
     }
+    if world == 1 and kind == "interp" and steps:
+        # the fixed cost the multi-GPU step adds on every rank: packing the kept rows of this launch (srt_pack_rows_device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        parallel.pack_rows_device(o["rows"], o["nrows"], p.outputper)  # (allocates the reused buffer)
+        torch.cuda.synchronize(dev)
+        e0.record()
+        _, off = parallel.pack_rows_device(o["rows"], o["nrows"], p.outputper)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        res["pack_ms_one_gpu"] = e0.elapsed_time(e1)
+        res["packed_bytes_one_gpu"] = int(off[-1]) * 160
+    if world == 1 and kind == "ngo" and steps and hi > lo:
+        # what bounds this launch from below: its longest rays alone (<= 8 rays = one wave in tail mode, srt_models.hpp):
+        # their sequential attempts x the tail-mode trip time
+        nr = res["nrows"]
+        longest = np.argsort(-nr.astype(np.int64), kind="stable")[:8]
+        sub = DeviceBatch(model, p, pos0[lo:hi][longest], dir0[lo:hi][longest], w0[lo:hi][longest], dev)
+        sub.launch(0)
+        torch.cuda.synchronize(dev)
+        sub.launch(0)
+        torch.cuda.synchronize(dev)
+        c8 = sub.out[0]["cnt"].cpu().numpy()
+        res["latency_floor_ms"] = model.launch_ms(0)
+        res["latency_floor_note"] = ("the launch's %d longest rays alone in one wave (tail mode): %d sequential attempt trips, "
+                                     "%.1f us per trip" % (len(longest), int(c8[3]), 1e3 * res["latency_floor_ms"] / max(int(c8[3]), 1)))
     if keep:
         res["batch"] = batch
     return res
+
+
+def pipelined_pass(ctx, name, rays_override=0, steps=3):
+    """`steps` steps through parallel.trace_sharded_pipelined (two sets of output buffers; the pack + gather of step k on a
+    side stream while step k + 1 traces), bracketed like the timed region.  Reported beside the serial headline; a failure
+    is reported as text, it does not touch the headline."""
+    from stanford_raytracer_amd import api, parallel, workloads as wl
+    from stanford_raytracer_amd.device_batch import DeviceBatch
+
+    args, torch, dev, dist, rank, world = ctx.args, ctx.torch, ctx.dev, ctx.dist, ctx.rank, ctx.world
+    try:
+        W = WORKLOADS[name]
+        kind = W["kind"]
+        per_gpu = rays_override or W["rays"]
+        total = per_gpu * world if W["scaling"] == "weak" else per_gpu
+        p = api.make_params(fixedstep=0, dt0=1e-3, dtmax=0.1, maxerr=5e-4, tmax=0.5, root=2, minalt=wl.MINALT,
+                            maxsteps=args.maxsteps or W["maxsteps"], outputper=W["outputper"], del_=W["del_"],
+                            refill_threshold=args.refill, ray_order=args.ray_order)
+        model, _, _ = make_model(ctx, kind, (args.grid or 256) if kind == "interp" else 0, (args.points or 825_000) if kind == "scattered" else 0)
+        pos0, dir0, w0 = wl.launch_set(total, W["seed"])
+        lo, hi = parallel.shard_bounds(total, rank, world)
+        batch = DeviceBatch(model, p, pos0[lo:hi], dir0[lo:hi], w0[lo:hi], dev, nbuf=2)
+        launch = lambda k: batch.trace(k % 2)
+        pack = lambda rows, nrows, slot: parallel.pack_rows_device(rows, nrows, p.outputper, slot=slot)
+        parallel.trace_sharded_pipelined(dist, total, 2, launch, pack)  # warm-up (allocates the pack buffers)
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        parallel.trace_sharded_pipelined(dist, total, steps, launch, pack)
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t0
+        rdev = dev if dist.get_backend() == "nccl" else torch.device("cpu")
+        t = torch.tensor([el], dtype=torch.float64, device=rdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        del batch
+        return {"steps": steps, "ms_per_step": 1e3 * float(t.cpu()[0]) / steps,
+                "note": "parallel.trace_sharded_pipelined: gather of step k overlapped with the trace of step k + 1; "
+                        "gather_ms_exposed = this ms_per_step - the trace kernel's time (max over ranks)"}
+    except Exception as e:  # pragma: no cover
+        return {"ms_per_step": None, "error": "%s: %s" % (type(e).__name__, e)}
 
 
 def describe(res):
@@ -350,8 +433,11 @@ def describe(res):
     p, kind = res["params"], res["kind"]
     what = {"interp": "interp_dens_model on %d^3 x4 lnN grid (tricubic)" % res["grid"],
             "ngo": "ngo_dens_model", "scattered": "scattered_interp_dens_model (%d samples, order 2, window 1.5/5)" % res["points"]}[kind]
-    return "%s: %d rays (%s scaling), %s, dipole B, adaptive RK45, maxsteps %d, outputper %d" % (
-        res["workload"], res["total_rays"], res["scaling"], what, p.maxsteps, p.outputper)
+    fld = res.get("field", (0, 0))
+    bname = {(0, 0): "dipole B", (1, 0): "IGRF B (use_igrf=1)", (0, 1): "dipole + T04_s B (use_tsyganenko=1)",
+             (1, 1): "IGRF + T04_s B"}[tuple(fld)]
+    return "%s: %d rays (%s scaling), %s, %s, adaptive RK45, maxsteps %d, outputper %d" % (
+        res["workload"], res["total_rays"], res["scaling"], what, bname, p.maxsteps, p.outputper)
 
 
 def detail_of(res):
@@ -395,8 +481,12 @@ def main():
                                "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES"],
                               child_args_for(args, "ngo100k"))
             other_pmc["ngo100k"] = v if v is not None else {"error": err}
-            t, err = live_traffic(args, "scattered825k", rays=100_000)
+            t, err = live_traffic(args, "scattered825k")  # the full 1M-ray launch: measured, not extrapolated
             other_pmc["scattered825k"] = t if t is not None else {"error": err}
+            for name in ("interp_igrf200k", "interp_t04_64k"):  # field tails: fp32 + fp64 VALU mix of one launch
+                progress("counter pass (VALU instruction mix) over one launch of %s" % name)
+                v, err = pmc_pass(VALU_MIX_COUNTERS, child_args_for(args, name))
+                other_pmc[name] = v if v is not None else {"error": err}
 
     import torch
 
@@ -435,11 +525,20 @@ def main():
     if traffic is None and traffic_note and rank == 0:
         sys.stderr.write("bench.py: roofline.traffic unavailable -- %s\n" % traffic_note)
 
+    # ---- N > 1: the same steps with the pack + gather of step k behind the trace of step k + 1 (outside the timed region) --
+    pipe = None
+    if world > 1 and res["gather"]:
+        pipe = pipelined_pass(ctx, args.workload, rays_override=args.rays)
+        if pipe.get("ms_per_step") is not None:
+            pipe["gather_ms_exposed"] = pipe["ms_per_step"] - res["kernel_ms"]
+            pipe["serial_ms_per_step"] = res["ms_per_step"]
+
     # ---- the other BASELINE configs, one short timed run each (outside the headline's timed region) ----------------
     other = {}
     if want_other:
         if world == 1:
-            for name, st, wu in (("ngo100k", 3, 1), ("scattered825k", 1, 0), ("interp4m", 1, 1)):
+            for name, st, wu in (("ngo100k", 3, 1), ("scattered825k", 1, 0), ("interp4m", 1, 1), ("interp_igrf200k", 2, 1),
+                                 ("interp_t04_64k", 2, 1)):
                 progress("other config %s" % name)
                 other[name] = other_config_line(ctx, run_workload(ctx, name, st, wu), other_pmc.get(name))
         else:
@@ -490,8 +589,14 @@ def main():
             "roofline": roofline_of(res, k_ms, steps_rank0, traffic, traffic_note, stream_gbs, khash),
             "detail": detail_of(res),
         }
+        if world == 1 and "pack_ms_one_gpu" in res:
+            out["multi_gpu_parts"] = {"pack_ms": res["pack_ms_one_gpu"], "packed_bytes": res["packed_bytes_one_gpu"],
+                                      "note": "the fixed per-rank cost of a multi-GPU step measured here on one GPU: packing the kept rows "
+                                              "of this launch (srt_pack_rows_device, after the timed region); a peer then sends "
+                                              "packed_bytes over one xGMI link"}
         if world > 1:
             out["multi_gpu"] = {"gather_ms": res["gather_ms"], "pack_ms": res["pack_ms"], "kernel_ms_max_over_ranks": res["kernel_ms"],
+                                "pipelined": pipe,
                                 "gather_bytes_into_rank0": res["gather_bytes"],
                                 "gather_GBs": (res["gather_bytes"] / (res["gather_ms"] * 1e-3) / 1e9) if res["gather_ms"] else None,
                                 "note": "per step, max over ranks: trace (kernel_ms) + pack + variable-length gather of the kept rows "
@@ -581,22 +686,48 @@ def other_config_line(ctx, res, pmc):
         elif pmc:
             rf["source"] = "unavailable: %s" % pmc["error"]
         line["roofline"] = rf
+        if "latency_floor_ms" in res:
+            line["latency_floor_ms"] = res["latency_floor_ms"]
+            line["latency_floor_note"] = res["latency_floor_note"]
+    elif kind == "interp" and tuple(res.get("field", (0, 0))) != (0, 0):
+        rf = {"bound": "valu", "unit": "TFLOP/s", "peak": {"fp64": FP64_VALU_PEAK_TFLOPS, "fp32": FP32_VALU_PEAK_TFLOPS},
+              "achieved": None, "frac": None}
+        if pmc and "error" not in pmc:
+            f64 = 2.0 * pmc["SQ_INSTS_VALU_FMA_F64"] + pmc["SQ_INSTS_VALU_MUL_F64"] + pmc["SQ_INSTS_VALU_ADD_F64"]
+            f32 = 2.0 * pmc["SQ_INSTS_VALU_FMA_F32"] + pmc["SQ_INSTS_VALU_MUL_F32"] + pmc["SQ_INSTS_VALU_ADD_F32"]
+            # the counter pass traced one launch of this same workload; instructions per launch carry over, time is this run's
+            t = k_ms * 1e-3
+            a64, a32 = (f64 * 64.0 / t / 1e12, f32 * 64.0 / t / 1e12) if t > 0 else (None, None)
+            rf.update({"achieved": {"fp64": a64, "fp32": a32},
+                       # share of the vector ALU's issue capacity the arithmetic instructions take (wave-instruction slots;
+                       # lanes switched off by EXEC still occupy theirs)
+                       "frac": (a64 / FP64_VALU_PEAK_TFLOPS + a32 / FP32_VALU_PEAK_TFLOPS) if t > 0 else None,
+                       "valu_busy": pmc["SQ_ACTIVE_INST_VALU"] / max(pmc["SQ_WAVE_CYCLES"], 1.0),
+                       "wave_instructions": {k: pmc[k] for k in pmc if k.startswith("SQ_INSTS_VALU_")},
+                       "source": "live: rocprofv3 --pmc child pass of one launch of this workload"})
+        elif pmc:
+            rf["source"] = "unavailable: %s" % pmc["error"]
+        line["roofline"] = rf
     elif kind == "scattered":
         rf = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "achieved": None, "frac": None}
         if pmc and "error" not in pmc and pmc.get("accepted_steps_of_counted_launch"):
-            # the counter passes traced 100k rays of the same launch-set generator against the same sample set: bytes per
-            # accepted step carry over to the 1M-ray launch timed here, the launch time does not
+            # the counter passes traced this same launch (same rays, same sample set): measured bytes of the whole launch
             bps = pmc["bytes_per_launch"] / pmc["accepted_steps_of_counted_launch"]
-            ach = bps * steps_rank0 / (k_ms * 1e-3) / 1e9 if k_ms > 0 else None
+            same = pmc["accepted_steps_of_counted_launch"] == steps_rank0
+            tb = pmc["bytes_per_launch"] if same else bps * steps_rank0
+            ach = tb / (k_ms * 1e-3) / 1e9 if k_ms > 0 else None
             rf.update({"achieved": ach, "frac": ach / HBM_PEAK_GBS if ach else None, "traffic_bytes_per_accepted_step": bps,
-                       "traffic": bps * steps_rank0,
-                       "source": pmc["source"] + " on a 100k-ray launch of the same workload (measured bytes per accepted step x "
-                                 "this launch's accepted steps)"})
+                       "traffic": tb, "FETCH_SIZE_KB": pmc.get("FETCH_SIZE_KB"), "WRITE_SIZE_KB": pmc.get("WRITE_SIZE_KB"),
+                       "source": pmc["source"] + (" over this launch itself (%d rays)" % res["total_rays"] if same else
+                                                  " on a launch with %s accepted steps, scaled to this one's" % pmc["accepted_steps_of_counted_launch"])})
         elif pmc:
             rf["source"] = "unavailable: %s" % pmc.get("error", "no step count from the counter pass")
         line["roofline"] = rf
     else:
         line["roofline"] = {"bound": "hbm", "note": "same kernel as the headline: see roofline"}
+    if "pack_ms_one_gpu" in res:
+        line["pack_ms"] = res["pack_ms_one_gpu"]
+        line["packed_bytes"] = res["packed_bytes_one_gpu"]
     return line
 
 

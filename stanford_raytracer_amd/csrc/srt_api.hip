@@ -586,7 +586,8 @@ extern "C" int srt_model_create_interp(int nspec, int nx, int ny, int nz, const 
                                        const double *qs, const double *ms, const double *F,
                                        const double *const *derivs, int yearday, int msec, srt_model **out) {
   if (!bounds || !qs || !ms || !F || !out) return srt_set_error(SRT_EINVAL, "null argument");
-  if (nspec < 1 || nspec > SRT_MAXSPEC) return srt_set_error(SRT_EINVAL, "nspec=%d unsupported (1..%d)", nspec, SRT_MAXSPEC);
+  if (nspec < 1 || nspec > SRT_MAXSPEC)
+    return srt_set_error(SRT_EINVAL, "nspec=%d unsupported (1..%d species: SRT_MAXSPEC, include/srt.h)", nspec, SRT_MAXSPEC);
   if (nx < 2 || ny < 2 || nz < 2) return srt_set_error(SRT_EINVAL, "grid must have >= 2 nodes per axis");
   int rc = ensure_init();
   if (rc) return rc;
@@ -790,7 +791,8 @@ extern "C" int srt_model_create_scattered_file(const char *ptsfile, int yearday,
                                                int order, int exact, double local_window_scale, srt_model **out) {
   if (!ptsfile || !out) return srt_set_error(SRT_EINVAL, "null argument");
   if (order < 0 || order > 3) // tabular_monomials covers degrees 0..3 (lsinterp_mod.f95:76-99); beyond: generate_monomials, not built
-    return srt_set_error(SRT_EINVAL, "scattered_interp_order=%d: orders 0..3 are supported", order);
+    return srt_set_error(SRT_EINVAL, "scattered_interp_order=%d: orders 0..3 are supported (the reference's generate_monomials orders, "
+                                     "N >= 4, are not built: stay on the Fortran path for them)", order);
   if (!(window_scale > 0) || !(local_window_scale > 0)) return srt_set_error(SRT_EINVAL, "window scales must be > 0");
   int rc = ensure_init();
   if (rc) return rc;

@@ -275,7 +275,7 @@ static bool read_grid_file_records(const char *path, GridFile &g, std::string &e
   double v[8];
   if (r.read(5, v) != 5) { err = "size header incomplete"; return false; }
   g.compder = (int)v[0]; g.nspec = (int)v[1]; g.nx = (int)v[2]; g.ny = (int)v[3]; g.nz = (int)v[4];
-  if (g.nspec < 1 || g.nspec > 4) { err = "nspec must be 1..4"; return false; }
+  if (g.nspec < 1 || g.nspec > 4) { err = "nspec must be 1..4 (SRT_MAXSPEC: this library carries at most four species; see INTEGRATION.md section 1)"; return false; }
   if (g.nx < 2 || g.ny < 2 || g.nz < 2) { err = "grid needs >= 2 nodes per axis"; return false; }
   if (r.read(6, g.bounds) != 6) { err = "bounds incomplete"; return false; }
   if (r.read(g.nspec, g.qs) != g.nspec) { err = "charges incomplete"; return false; }
@@ -358,7 +358,7 @@ static bool read_grid_binary(const char *path, GridFile &g, std::string &err) {
   GridBinHeader h;
   memcpy(&h, mf.p, sizeof h);
   g.compder = h.compder; g.nspec = h.nspec; g.nx = h.nx; g.ny = h.ny; g.nz = h.nz;
-  if (g.nspec < 1 || g.nspec > 4) { err = "nspec must be 1..4"; return false; }
+  if (g.nspec < 1 || g.nspec > 4) { err = "nspec must be 1..4 (SRT_MAXSPEC: this library carries at most four species; see INTEGRATION.md section 1)"; return false; }
   if (g.nx < 2 || g.ny < 2 || g.nz < 2) { err = "grid needs >= 2 nodes per axis"; return false; }
   memcpy(g.bounds, h.bounds, sizeof g.bounds);
   memcpy(g.qs, h.qs, sizeof g.qs);
@@ -455,7 +455,7 @@ bool read_grid_file(const char *path, GridFile &g, std::string &err) {
   };
   if (!record(5)) { err = "size header incomplete"; return false; }
   g.compder = (int)hv[0]; g.nspec = (int)hv[1]; g.nx = (int)hv[2]; g.ny = (int)hv[3]; g.nz = (int)hv[4];
-  if (g.nspec < 1 || g.nspec > 4) { err = "nspec must be 1..4"; return false; }
+  if (g.nspec < 1 || g.nspec > 4) { err = "nspec must be 1..4 (SRT_MAXSPEC: this library carries at most four species; see INTEGRATION.md section 1)"; return false; }
   if (g.nx < 2 || g.ny < 2 || g.nz < 2) { err = "grid needs >= 2 nodes per axis"; return false; }
   if (!record(6)) { err = "bounds incomplete"; return false; }
   if (!record(g.nspec)) { err = "charges incomplete"; return false; }

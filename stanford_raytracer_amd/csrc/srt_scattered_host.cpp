@@ -150,7 +150,7 @@ bool build_scattered(const char *path, double window_scale, ScatteredHost &out, 
       double hdr[7];
       if (r.read(7, hdr) != 7) { err = "header (nspec + bounds) incomplete"; return false; }
       nspec = (int)hdr[0];
-      if (nspec < 1 || nspec > 4) { err = "nspec must be 1..4"; return false; }
+      if (nspec < 1 || nspec > 4) { err = "nspec must be 1..4 (SRT_MAXSPEC: this library carries at most four species; see INTEGRATION.md section 1)"; return false; }
       out.nspec = nspec;
       if (r.read(nspec, out.qs) != nspec || r.read(nspec, out.ms) != nspec) { err = "charges/masses incomplete"; return false; }
       double row[8];

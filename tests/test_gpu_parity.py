@@ -218,20 +218,44 @@ def test_scattered_vs_oracle_ladder(gpu_models, oracle_scattered):
     assert np.median(ex) <= 1e-5 and np.percentile(ex, 90) <= 1e-3   # d(ln N) over a 10 m stencil: 1e-13 / 1e-6 amplification
 
 
-def test_scattered_trajectories(golden, gpu_models):
+def test_scattered_trajectories(golden, gpu_models, oracle_scattered, pointsfile):
+    """The reference's own adaptive rows of the 24 scattered-model launch rays.  Bars: what the ORACLE does to itself under a
+    1e-9 shift of the launch points (the machinery of tests/test_gpu_trajectory_stats.py), not constants -- the oracle
+    (with the reference's tree-root quirk, perm_seed = 2) is first held to the reference on the same rays."""
+    from oracle import oracle
+    from test_gpu_trajectory_stats import compare
+
     rays, prm = golden["g4_scattered_rays"], golden["g4_scattered_launch_params"]
     ref_rows, ref_n, ref_stop = (golden["g4_scattered_launch_" + k] for k in ("rows", "nrows", "stop"))
-    rows, nrows, stop, _ = gpu_models["scattered"].trace(rays[:, :3], rays[:, 3:6], rays[:, 6], outputper=1, dt0=prm[0],
-                                                         dtmax=prm[1], tmax=prm[2], maxerr=prm[3], minalt=prm[4],
-                                                         maxsteps=int(prm[5]), root=int(prm[6]), fixedstep=0, del_=1e-6)
-    assert np.mean(stop == ref_stop) >= 0.9
+    kw = dict(dt0=prm[0], dtmax=prm[1], tmax=prm[2], maxerr=prm[3], minalt=prm[4], maxsteps=int(prm[5]), root=int(prm[6]),
+              fixedstep=0, del_=1e-6)
+    cap = int(ref_rows.shape[1])
+    rows, nrows, stop, _ = gpu_models["scattered"].trace(rays[:, :3], rays[:, 3:6], rays[:, 6], outputper=1, **kw)
+    ref = (ref_rows, ref_n, ref_stop)
+    # yardstick 1: the oracle built like the reference (its tree root keeps spacing 0) against the reference's rows
+    oq = oracle.Model.scattered_file(pointsfile, perm_seed=2)
+    oref = compare(oq.trace(rays[:, :3], rays[:, 3:6], rays[:, 6], capacity=cap, **kw)[:3], ref, prm[2])
+    # yardstick 2: the oracle against itself, launch points shifted by 1e-9 (~1 cm)
+    base = oracle_scattered.trace(rays[:, :3], rays[:, 3:6], rays[:, 6], capacity=cap, **kw)[:3]
+    yard = None
+    for eps in (1e-9, -1e-9):
+        pert = oracle_scattered.trace(rays[:, :3] * (1 + eps), rays[:, 3:6], rays[:, 6], capacity=cap, **kw)[:3]
+        c = compare(pert, base, prm[2])
+        yard = c if yard is None else {k: (min if k in ("stop_agree", "same_t") else max)(yard[k], c[k]) for k in c}
+    mine = compare((rows[:, :cap], nrows, stop), ref, prm[2])
+    msg = "\nGPU vs reference: %s\noracle vs reference: %s\noracle vs oracle(launch shifted 1e-9): %s" % (mine, oref, yard)
+    print(msg)
     both = (nrows > 1) & (ref_n > 1)
     assert np.array_equal(rows[both, 0, 1:4], ref_rows[both, 0, 1:4])
     e = np.abs(rows[both, 0, 16:20] - ref_rows[both, 0, 16:20]) / ref_rows[both, 0, 16:20]
     assert np.percentile(e, 90) <= 1e-9
-    d1 = vrel(rows[both, 1, 1:4], ref_rows[both, 1, 1:4])
-    assert np.median(d1) <= 1e-6
-    assert abs(int(nrows.sum()) - int(ref_n.sum())) <= 0.25 * ref_n.sum()
+    worst = {k: (min if k in ("stop_agree", "same_t") else max)(yard[k], oref[k]) for k in yard}
+    n = len(ref_n)
+    assert mine["curve_median"] <= 3 * max(worst["curve_median"], 7e-8), msg
+    assert mine["curve_p90"] <= 3 * max(worst["curve_p90"], 4e-5), msg
+    assert mine["stop_agree"] >= worst["stop_agree"] - 1.5 / n, msg        # at most one more ray of the 24 changes fate
+    assert mine["same_t"] >= worst["same_t"] - 2.5 / n, msg
+    assert mine["rows_rel"] <= max(3 * worst["rows_rel"], 0.02), msg
 
 
 # ---- interp model: shapes the cubic 4-species fixture does not exercise ------------------------------------------
