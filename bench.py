@@ -89,7 +89,7 @@ def parse_args(argv=None):
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams the steps alternate on at N=1 (1 = strictly serial, the default: kernel time == step "
                          "time; 2 lets the drain of one launch overlap the ramp-up of the next, +5 %%)")
-    ap.add_argument("--ray-order", type=int, default=1, choices=[0, 1],
+    ap.add_argument("--ray-order", type=int, default=1, choices=[0, 1, 2],
                     help="srt_params.ray_order: 1 = the library works through the launch set sorted by launch cell "
                          "(device sort inside the timed region; SURVEY 8d allows this permutation), 0 = as given")
     ap.add_argument("--traffic", default="auto", choices=["auto", "live", "file", "off"],

@@ -66,7 +66,9 @@ typedef struct srt_params {
   int32_t ray_order;            /* order in which the launch set is WORKED ON (results and their order are unchanged):
                                    0 = as given; 1 = sorted on the device by the Morton code of the launch cell, so
                                    that the lanes of a wave start in neighbouring cells of the interp grid and share
-                                   coefficient lines (SURVEY.md 8d allows this input permutation; other models ignore it) */
+                                   coefficient lines (SURVEY.md 8d allows this input permutation; other models ignore it);
+                                   2 = as 1 with the rays that are likely to stop early (above 6 kHz, launched inwards)
+                                   behind all others -- an experiment switch for the launch's tail, not a gain */
 } srt_params;
 
 typedef struct srt_model srt_model; /* opaque; owns device copies of all model data */

@@ -9,6 +9,7 @@
 #include "srt_host.hpp"
 
 #include <charconv>
+#include <cerrno>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -666,7 +667,7 @@ extern "C" int64_t srt_read_ray_file(const char *path, int32_t *nspec_out, doubl
     for (int64_t r = 0; r < nrec; ++r) {
       const double *v = all.data() + (size_t)r * per;
       if ((int)v[19] != nspec) return srt_set_error(SRT_EIO, "%s: record %lld has nspec %g", path, (long long)r + 1, v[19]);
-      if (r == 0 || v[0] != all[(size_t)(r - 1) * per]) ++nray;
+      if (r == 0 || v[0] != all[(size_t)(r - 1) * per] || v[2] == 0.0) ++nray; // (a ray's first record is its row 0: t = 0)
     }
   }
   const int64_t na = nray ? nray : 1, nr = nrec ? nrec : 1;
@@ -685,7 +686,7 @@ extern "C" int64_t srt_read_ray_file(const char *path, int32_t *nspec_out, doubl
   int64_t ray = -1;
   for (int64_t r = 0; r < nrec; ++r) {
     const double *v = all.data() + (size_t)r * per;
-    if (r == 0 || v[0] != all[(size_t)(r - 1) * per]) {
+    if (r == 0 || v[0] != all[(size_t)(r - 1) * per] || v[2] == 0.0) { // (so files appended to, which repeat ray numbers, keep their rays apart)
       ++ray;
       (*raynum)[ray] = (int64_t)v[0];
       (*stopcond)[ray] = (int32_t)v[1];
@@ -746,6 +747,10 @@ extern "C" int srt_write_ray_file(const char *path, int append, int64_t raynum0,
                                   const double *rows, const int32_t *nrows, const int32_t *stopcond) {
   if (!path || !p || !qs || !ms || !w0 || !rows || !nrows || !stopcond) return srt_set_error(SRT_EINVAL, "null argument");
   if (nspec < 1 || nspec > SRT_MAXSPEC) return srt_set_error(SRT_EINVAL, "nspec out of range");
+  // the record's ray number is an i10 field (raytracer_driver.f95:1197): beyond ten digits Fortran prints asterisks and the
+  // fixed-length record could not hold the number -- refused rather than shifted or truncated
+  if (raynum0 < 0 || nrays < 0 || raynum0 + nrays - 1 > 9999999999ll)
+    return srt_set_error(SRT_EINVAL, "ray numbers %lld .. %lld do not fit the record's i10 field", (long long)raynum0, (long long)(raynum0 + nrays - 1));
   const int slots = srt_rows_per_ray(p);
   const int per = p->outputper < 1 ? 1 : p->outputper;
   const size_t L = 20 + 17 * 24 + 10 + (size_t)4 * nspec * 24 + 1;
@@ -787,6 +792,7 @@ extern "C" int srt_write_ray_file(const char *path, int append, int64_t raynum0,
       size_t done = 0;
       while (done < fill) {
         ssize_t w = pwrite(fd, buf.data() + done, fill - done, off + (off_t)done);
+        if (w < 0 && errno == EINTR) continue; // interrupted before anything was written: again
         if (w <= 0) {
           fail[t] = 1;
           return;

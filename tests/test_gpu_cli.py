@@ -90,6 +90,24 @@ def test_cli_adaptive_model3_matches_the_reference_drivers_file(tmp_path, grid16
             assert vrel(a[1, 3:6], r[1, 3:6]) <= 1e-3
     assert stop_agree >= 14
     assert abs(rows_mine - rows_ref) <= 0.1 * rows_ref
+    # rays whose step sequences do not split: the WHOLE time-stamp column is equal (every kept row), and so are the record
+    # counts; positions then differ only by what 16 .. 2000 steps amplify
+    whole, first = 0, 0
+    for ray in range(1, 17):
+        a, r = mine[mine[:, 0] == ray], ref[ref[:, 0] == ray]
+        n = min(len(a), len(r))
+        same = int(np.argmax(a[:n, 2] != r[:n, 2])) if np.any(a[:n, 2] != r[:n, 2]) else n   # kept rows before the split
+        first += int(same >= 2)
+        if same == n and len(a) == len(r):
+            whole += 1
+            assert np.array_equal(a[:, 2], r[:, 2]) and a[0, 1] == r[0, 1]
+            assert vrel(a[1:, 3:6], r[1:, 3:6]).max() <= 1e-3
+        elif same >= 2:  # up to the split the curves coincide (same knots): SURVEY A-9's ladder at <= 100 steps
+            assert vrel(a[1:same, 3:6], r[1:same, 3:6]).max() <= 1e-3
+    # (no floor on these counts: with outputper = 16 the first kept row already lies 16 adaptive steps after the launch, where
+    # the interp model's step sequences have split for most rays -- measured: 1 of 16 keeps it; the time-grid agreement of the
+    # first steps is asserted at outputper = 1, on 1 024 rays, in tests/test_gpu_trajectory_stats.py)
+    print("driver golden: %d of 16 rays keep the reference's whole time grid, %d its first kept row" % (whole, first))
 
 
 def test_cli_devices_flag_shards_and_keeps_ray_order(tmp_path, cfgfiles):

@@ -289,3 +289,27 @@ def test_ray_file_reader(tmp_path, monkeypatch):
     bad.write_text(open(os.path.join(GOLDEN_DIR, "config1_outputper25.ray")).read()[:-400])     # a truncated last record
     with pytest.raises(api.SrtError):
         api.read_ray_file(str(bad))
+
+
+def test_ray_file_edge_cases_of_the_record_head(tmp_path):
+    """The i10 ray-number field cannot hold more than ten digits (Fortran prints asterisks): refused, not shifted; a file that
+    was appended to and repeats ray numbers keeps its rays apart (a ray's first record is its row 0, t = 0)."""
+    from stanford_raytracer_amd import api, workloads as wl
+
+    p = api.make_params(maxsteps=3, outputper=1)
+    rows = np.zeros((2, 3, 20))
+    rows[:, 1, 0], rows[:, 2, 0] = 1e-3, 2e-3        # t = 0, 1e-3, 2e-3
+    rows[:, :, 1:] = 1.5
+    nrows, stop, w0 = np.array([3, 2], dtype=np.int32), np.array([0, 6], dtype=np.int32), np.array([1e4, 2e4])
+    out = tmp_path / "big.ray"
+    with pytest.raises(api.SrtError, match="i10"):
+        api.write_ray_file(str(out), (4, wl.QS, wl.MS), p, w0, rows, nrows, stop, raynum0=9_999_999_999)
+    api.write_ray_file(str(out), (4, wl.QS, wl.MS), p, w0, rows, nrows, stop, raynum0=9_999_999_998)   # ..98 and ..99 still fit
+    r = api.read_ray_file(str(out))
+    assert r["raynum"].tolist() == [9_999_999_998, 9_999_999_999] and r["kept"].tolist() == [3, 2] and r["stopcond"].tolist() == [0, 6]
+    # the same two rays appended under the SAME numbers: four rays, not two
+    ap = tmp_path / "appended.ray"
+    api.write_ray_file(str(ap), (4, wl.QS, wl.MS), p, w0, rows, nrows, stop, raynum0=1)
+    api.write_ray_file(str(ap), (4, wl.QS, wl.MS), p, w0[:1], rows[:1], nrows[:1], stop[:1], raynum0=2, append=True)
+    r = api.read_ray_file(str(ap))
+    assert r["raynum"].tolist() == [1, 2, 2] and r["kept"].tolist() == [3, 2, 3] and r["w0"].tolist() == [1e4, 2e4, 1e4]

@@ -148,3 +148,58 @@ def test_gpu_scattered_fixed_step(g1, gpu_models, oracle_scattered):
         d = _divergence(rows, nrows, ref_rows, ref_n, r)
         bound = 10 * max(yard[r], LADDER.get(r, 7e-8), 1e-6)               # 1e-6: dF/dx over a 10 m stencil (test_oracle_golden G4)
         assert d <= bound, "row %d: position divergence %.2e > %.2e" % (r, d, bound)
+
+
+# ---- the first adaptive attempt: the one trajectory file the reference's tree holds --------------
+def _growth_prefix(times):
+    """leading time stamps that follow t_{n+1} = t_n + 1e-3 * 1.25**n exactly (the controller growing dt from the first step)"""
+    t, dt, n = 0.0, 1e-3, 0
+    while n + 1 < len(times) and abs(times[n + 1] - (t + dt)) <= 2e-15 * (t + dt):  # (the file prints 16 digits)
+        t, dt, n = t + dt, dt * 1.25, n + 1
+    return n
+
+
+def test_first_attempt_policy_1_is_what_the_references_own_output_shows(oracle_models):
+    """gcpm/output.ray of the reference tree (its gfortran-built binary): dt grows by 1.25 from the FIRST accepted step --
+    policy 1.  The oracle under policy 1 produces exactly those time stamps on rays whose error estimate stays below
+    maxerr / 100; under policy 0 (flang's MAX) the first step is never grown."""
+    ref_t = np.loadtxt(os.path.join(GOLDEN_DIR, "reference_gcpm_output_times.txt"))
+    nref = _growth_prefix(ref_t)
+    assert nref >= 8 and np.allclose(ref_t[1:4], [1e-3, 2.25e-3, 3.8125e-3], rtol=1e-15, atol=0)
+    from stanford_raytracer_amd import workloads as wl
+
+    pos, d, w = wl.launch_set(64, 11)
+    kw = dict(fixedstep=0, dt0=1e-3, dtmax=0.1, tmax=0.1, maxerr=5e-4, maxsteps=40, del_=DELS["ngo"])
+    r1, n1, _, _ = oracle_models["ngo"].trace(pos, d, w, capacity=40, first_attempt_policy=1, **kw)
+    r0, n0, _, _ = oracle_models["ngo"].trace(pos, d, w, capacity=40, first_attempt_policy=0, **kw)
+    grow1 = np.array([_growth_prefix(r1[i, :n1[i], 0]) for i in range(len(w))])
+    grow0 = np.array([_growth_prefix(r0[i, :n0[i], 0]) for i in range(len(w))])
+    assert (grow1 >= 3).mean() >= 0.25            # rays with a small error estimate reproduce the file's 0, 1e-3, 2.25e-3, 3.8125e-3
+    assert grow0.max() <= 1                        # policy 0: row 2 sits at 2e-3 at the earliest, never at 2.25e-3
+    sel = np.where(grow1 >= 3)[0]
+    assert np.allclose(r1[sel[0], :4, 0], ref_t[:4], rtol=2e-15, atol=0)
+
+
+@pytest.mark.gpu
+def test_cli_default_first_attempt_follows_the_references_own_output(tmp_path, cfgfiles):
+    """The CLI's default (no --first_attempt_policy flag) is policy 1: its .ray file shows the time stamps of the reference's
+    own gcpm/output.ray on rays with a small error estimate."""
+    import subprocess
+
+    from conftest import parse_ray_file
+    from stanford_raytracer_amd import build, workloads as wl
+
+    ref_t = np.loadtxt(os.path.join(GOLDEN_DIR, "reference_gcpm_output_times.txt"))
+    pos, d, w = wl.launch_set(64, 11)
+    rays, out = str(tmp_path / "rays.txt"), str(tmp_path / "out.ray")
+    wl.write_rays_file(rays, pos, d, w)
+    cmd = [build.CLI, "--outputper=1", "--dt0=1e-3", "--dtmax=0.1", "--tmax=0.1", "--root=2", "--fixedstep=0", "--maxerr=5e-4",
+           "--maxsteps=40", "--minalt=%r" % wl.MINALT, "--inputraysfile=" + rays, "--outputfile=" + out, "--modelnum=1",
+           "--yearday=2010001", "--milliseconds_day=0", "--use_tsyganenko=0", "--use_igrf=0", "--ngo_configfile=" + cfgfiles["ngo"]]
+    subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL)
+    rec = parse_ray_file(out)
+    hits = 0
+    for r in np.unique(rec[:, 0]):
+        t = rec[rec[:, 0] == r, 2]
+        hits += int(len(t) >= 4 and np.allclose(t[:4], ref_t[:4], rtol=2e-15, atol=0))
+    assert hits >= 16
