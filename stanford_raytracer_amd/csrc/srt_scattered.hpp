@@ -918,13 +918,14 @@ struct ScatteredModel {
       r[1] = qb;
       r[2] = qc;
       r[3] = d2_t{qd.x, 0.0};
-      if (k < side.cap) { // what the weights need waits in LDS ..
+      // (always, although only a list longer than the side arrays reads them back: a trip whose number of stores depends on
+      // the path makes the compiler's wait for the next gather wait for these stores as well)
+      r[4] = d2_t{rc, 0.0};
+      r[5] = d2_t{ca, sa};
+      if (k < side.cap) { // what the weights need waits in LDS
         side.a[k] = qa;
         side.b[k] = d2_t{q2, rc};
         side.c[k] = d2_t{ca, sa};
-      } else { // .. or, for a list longer than the side arrays, in the record
-        r[4] = d2_t{rc, 0.0};
-        r[5] = d2_t{ca, sa};
       }
     }
     SRT_PHASE(1);
@@ -981,16 +982,7 @@ struct ScatteredModel {
     const double o7[3] = {pg[7][0] - pg[0][0], pg[7][1] - pg[0][1], pg[7][2] - pg[0][2]};
     const double o7sq = o7[0] * o7[0] + o7[1] * o7[1] + o7[2] * o7[2];
     const Side side = side_of(list, n_list);
-#pragma unroll 1
-    for (int k = lane; k < n_list; k += 64) {
-      d2_t s0, s1, s2;
-      if (k < side.cap) {
-        s0 = side.a[k], s1 = side.b[k], s2 = side.c[k];
-      } else { // (a list longer than the side arrays: back from the record)
-        const SRT_AS1 d2_t *r = (const SRT_AS1 d2_t *)(rec + (size_t)k * REC);
-        const d2_t c1 = r[1], c4 = r[4];
-        s0 = r[0], s1 = d2_t{c1.x, c4.x}, s2 = r[5];
-      }
+    auto weigh = [&](int k, const d2_t s0, const d2_t s1, const d2_t s2) {
       const double q0 = s0.x, q1 = s0.y, q2 = s1.x, rc = s1.y, ca = s2.x, sa = s2.y;
       const double dc[3] = {q0 - pg[0][0], q1 - pg[0][1], q2 - pg[0][2]};
       const double ssc = dc[0] * dc[0] + dc[1] * dc[1] + dc[2] * dc[2];
@@ -1060,6 +1052,18 @@ struct ScatteredModel {
       r[5] = d2_t{w8[2], w8[3]};
       r[6] = d2_t{w8[4], w8[5]};
       r[7] = d2_t{w8[6], w8[7]};
+    };
+    // the samples whose {x, y, z, r_c, cos, sin} wait in LDS: no load from device memory in this loop, so nothing in it ever
+    // waits for the previous trip's stores
+    const int nlds = n_list < side.cap ? n_list : side.cap;
+#pragma unroll 1
+    for (int k = lane; k < nlds; k += 64) weigh(k, side.a[k], side.b[k], side.c[k]);
+    // a list longer than the side arrays: the rest back from their records
+#pragma unroll 1
+    for (int k = nlds + lane; k < n_list; k += 64) {
+      const SRT_AS1 d2_t *r = (const SRT_AS1 d2_t *)(rec + (size_t)k * REC);
+      const d2_t c0 = r[0], c1 = r[1], c4 = r[4], c5 = r[5];
+      weigh(k, c0, d2_t{c1.x, c4.x}, c5);
     }
     __syncthreads(); // block == one wave: the weights written above are read by other lanes next
     SRT_PHASE(3);
