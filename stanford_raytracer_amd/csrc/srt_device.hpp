@@ -10,6 +10,7 @@
 #include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "srt_fastmath.hpp"
 #include "srt_t04.hpp"
 
 namespace srt {
@@ -68,19 +69,6 @@ __device__ __forceinline__ bool field_is_igrf(const CM &cm) {
 }
 template <class CM>
 constexpr bool field_igrf_only() { return std::is_same<CM, CommonIgrfOnly>::value; }
-
-// a/b for operands well inside the exponent range (every division of the hot path: frequencies, densities,
-// field magnitudes, grid spacings).  This is the compiler's own fp64 division sequence -- v_rcp_f64, two Newton
-// steps on the reciprocal, quotient, one residual correction -- without the v_div_scale / v_div_fmas /
-// v_div_fixup wrapper that only matters for operands or quotients near the ends of the exponent range, so the
-// result is bit-identical to a/b wherever that wrapper would not have scaled (8 instructions instead of 11).
-__device__ __forceinline__ double fdiv(double a, double b) {
-  double r = __builtin_amdgcn_rcp(b);
-  r = fma(fma(-b, r, 1.0), r, r);
-  r = fma(fma(-b, r, 1.0), r, r);
-  double q = a * r;
-  return fma(fma(-b, q, a), r, q);
-}
 
 // ---------------------------------------------------------------------------------------------
 // IGRF_GSM -> IGRF_GSW_08 (geopack2008.for:55-185, GEOGSW_08 :1421-1457): spherical-harmonic synthesis of the main

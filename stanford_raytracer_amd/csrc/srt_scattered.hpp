@@ -171,75 +171,6 @@ static_assert(Moments::of_m(4) == mom::find(0, 1, 1) && Moments::of_m(9) == mom:
                   MomentsT<3>::of_m(12) == mom::find(1, 0, 2),
               "tabular_monomials order");
 
-// Elementary functions on the argument ranges of the shared path's per-sample passes (pass 1 / base pass of shared_fit: no
-// accumulators are alive there, so instruction count is what they cost).  Each is the textbook (fdlibm) kernel without the
-// library's range handling -- arguments here are never denormal, huge, negative or NaN-by-construction -- and agrees with
-// the library to <= 1-2 ulp; the weights they feed are common to the seven stencil points of a fit.
-namespace fm {
-// sqrt for 0 <= x, neither denormal nor near overflow: the compiler's own sequence (v_rsq_f64, one Goldschmidt step, two
-// residual corrections) without its range scaling
-__device__ __forceinline__ double sqrt_pos(double x) {
-  const double y = __builtin_amdgcn_rsq(x);
-  double g = x * y, h = 0.5 * y;
-  const double r = fma(-h, g, 0.5);
-  g = fma(g, r, g);
-  h = fma(h, r, h);
-  double d = fma(-g, g, x);
-  g = fma(d, h, g);
-  d = fma(-g, g, x);
-  g = fma(d, h, g);
-  return x == 0.0 ? 0.0 : g;
-}
-// sin and cos of a in [0, pi (1 + 2e-3)]: quadrant k = 0, 1, 2, t = a - k pi/2 in about [-pi/4, pi/4]
-__device__ __forceinline__ void sincos_0pi(double a, double &s, double &c) {
-  const double PIO2_HI = 1.57079632673412561417e+00, PIO2_LO = 6.07710050650619224932e-11; // k * hi is exact (33 bits)
-  const double kf = a > 0.75 * PI ? 2.0 : (a > 0.25 * PI ? 1.0 : 0.0);
-  const double t = fma(-kf, PIO2_LO, fma(-kf, PIO2_HI, a));
-  const double z = t * t;
-  const double rs = 8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 + z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
-  const double st = t + (z * t) * (-1.66666666666666324348e-01 + z * rs);
-  const double rc = z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 + z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
-  const double hz = 0.5 * z, w = 1.0 - hz;
-  const double ct = w + (((1.0 - w) - hz) + z * rc);
-  s = kf == 1.0 ? ct : (kf == 2.0 ? -st : st);
-  c = kf == 1.0 ? -st : (kf == 2.0 ? -ct : ct);
-}
-// ln x for a positive normal x
-__device__ __forceinline__ double log_pos(double x) {
-  double m = __builtin_amdgcn_frexp_mant(x); // [0.5, 1)
-  int e = __builtin_amdgcn_frexp_exp(x);
-  const bool low = m < 0.70710678118654752440;
-  m = low ? m + m : m; // [sqrt(1/2), sqrt 2)
-  e = low ? e - 1 : e;
-  const double f = m - 1.0, k = (double)e;
-  const double sq = fdiv(f, 2.0 + f), z = sq * sq, w = z * z;
-  const double t1 = w * (3.999999999940941908e-01 + w * (2.222219843214978396e-01 + w * 1.531383769920937332e-01));
-  const double t2 = z * (6.666666666666735130e-01 + w * (2.857142874366239149e-01 + w * (1.818357216161805012e-01 + w * 1.479819860511658591e-01)));
-  const double R = t2 + t1, hfsq = 0.5 * f * f;
-  return k * 6.93147180369123816490e-01 - ((hfsq - (sq * (hfsq + R) + k * 1.90821492927058770002e-10)) - f);
-}
-// e^y for y <= ~700 (underflows to 0 below -745)
-__device__ __forceinline__ double exp_any(double y) {
-  y = fmax(y, -800.0);
-  const double k = rint(y * 1.44269504088896338700e+00);
-  const double r = fma(-k, 1.90821492927058770002e-10, fma(-k, 6.93147180369123816490e-01, y)); // |r| <= 0.3466
-  double p = 1.0 / 6227020800.0;
-  p = fma(p, r, 1.0 / 479001600.0);
-  p = fma(p, r, 1.0 / 39916800.0);
-  p = fma(p, r, 1.0 / 3628800.0);
-  p = fma(p, r, 1.0 / 362880.0);
-  p = fma(p, r, 1.0 / 40320.0);
-  p = fma(p, r, 1.0 / 5040.0);
-  p = fma(p, r, 1.0 / 720.0);
-  p = fma(p, r, 1.0 / 120.0);
-  p = fma(p, r, 1.0 / 24.0);
-  p = fma(p, r, 1.0 / 6.0);
-  p = fma(p, r, 0.5);
-  p = fma(p, r, 1.0);
-  p = fma(p, r, 1.0);
-  return ldexp(p, (int)k);
-}
-} // namespace fm
 
 struct ScatteredModel {
   const double *pts;     // [npts][8]: x, y, z, lnN[4], nearest-sample distance
