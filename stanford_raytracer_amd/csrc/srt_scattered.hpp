@@ -532,7 +532,11 @@ struct ScatteredModel {
   //   [L + 2, L + 34) the groups' results on their way to the owner;  [L + 34, L + 50) cycle counters (timing builds);
   //   [L + 64, L + 320) the 64 lanes' candidate-block headers {centre x, y, z, entry count (int; -1 = none)}
 #ifndef SRT_SCAT_WAVES
-#define SRT_SCAT_WAVES 2 // waves per SIMD the cooperative kernels of this model are built for (1: 34.5 KiB of LDS, 512 registers)
+// Waves per SIMD the cooperative kernels of this model are built for: 1 = 34.5 KiB of LDS per wave, all 512 registers, a ring of
+// four record buffers; 2 = 18.5 KiB, <= 256 registers, two buffers.  Measured at BASELINE config[4]'s full size, same box:
+// 21.6 s per launch with 1, 24.3 s with 2 (at 100 k rays they tie): with two waves the SIMD's clock drops by what their
+// interleaving gains (cycle counters: 1.17 against 1.63 GHz) -- the kernel is bound by power, i.e. by instructions executed.
+#define SRT_SCAT_WAVES 1
 #endif
   static constexpr int WAVES_PER_EU = SRT_SCAT_WAVES;
   static constexpr int NBUF = WAVES_PER_EU == 2 ? 2 : 4;  // 64-record buffers of pass 2's ring
@@ -1621,7 +1625,7 @@ struct ScatteredModel {
         SRT_LDS d2_t *park = (SRT_LDS d2_t *)((SRT_LDS double *)lists + LDS_PARK);
         double val[4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) val[s] = (live && s < nspec) ? exp(fi.v[s]) : 0.0; // failed fit: fi = 0 -> Ns = 1
+        for (int s = 0; s < 4; ++s) val[s] = (live && s < nspec) ? fm::exp_any(fi.v[s]) : 0.0; // failed fit: fi = 0 -> Ns = 1
         if ((lane & 7) == 0) {
           park[2 * g] = d2_t{val[0], val[1]};
           park[2 * g + 1] = d2_t{val[2], val[3]};
