@@ -1432,6 +1432,15 @@ extern "C" int srt_trace_batch_device(srt_model *m, const srt_params *p, int64_t
     fprintf(stderr, "\n");
     memset(h, 0, sizeof h);
     HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(srt_phase_cycles), h, sizeof h));
+    unsigned long long ws[4];
+    float ms = 0.f;
+    HIP_OK(hipMemcpyFromSymbol(ws, HIP_SYMBOL(srt_wave_stats), sizeof ws));
+    HIP_OK(hipEventElapsedTime(&ms, sl.ev0, sl.ev1));
+    // (the timers of the eight XCDs are not aligned with each other: only a wave's own span means something)
+    fprintf(stderr, "srt wave stats: grid %lld, working waves %llu, launch %.1f ms, mean span of a working wave %.4g ticks = %.1f MHz if it ran for the whole launch\n",
+            grid, ws[0], ms, ws[0] ? (double)ws[1] / (double)ws[0] : 0.0, ws[0] ? (double)ws[1] / (double)ws[0] / (ms * 1e3) : 0.0);
+    const unsigned long long z[4] = {0ull, 0ull, ~0ull, 0ull};
+    HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(srt_wave_stats), z, sizeof z));
   }
 #endif
   sl.used = true;

@@ -280,6 +280,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WaveBudget<M
   bool first_attempt = true;
   unsigned long long acc_steps = 0, acc_attempts = 0, wave_trips = 0;
   const int threshold = P.refill_threshold > 0 ? P.refill_threshold : 1;
+#ifdef SRT_PHASE_TIMING
+  const unsigned long long srt_wave_t0 = __builtin_readcyclecounter();
+#endif
 #ifdef SRT_TRIP_TIMING
   if (threadIdx.x < 16) srt_tt_lds()[threadIdx.x] = 0ull;
   __syncthreads();
@@ -567,6 +570,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WaveBudget<M
 #ifdef SRT_TRIP_TIMING
   __syncthreads();
   if (threadIdx.x < 16) atomicAdd(&srt_trip_cycles[threadIdx.x], srt_tt_lds()[threadIdx.x]);
+#endif
+#ifdef SRT_PHASE_TIMING
+  if (lane == 0) {
+    const unsigned long long t_end = __builtin_readcyclecounter();
+    if (wave_trips > 0) {
+      atomicAdd(&srt_wave_stats[0], 1ull);
+      atomicAdd(&srt_wave_stats[1], t_end - srt_wave_t0);
+    }
+    atomicMin(&srt_wave_stats[2], srt_wave_t0);
+    atomicMax(&srt_wave_stats[3], t_end);
+  }
 #endif
   // per-wave totals
   for (int off = 32; off > 0; off >>= 1) {

@@ -30,6 +30,12 @@ __device__ __forceinline__ unsigned long long *srt_tt_lds() {
 }
 #endif
 
+#ifdef SRT_PHASE_TIMING
+// (timing builds) how the persistent waves of a trace launch ran: [0] waves that claimed at least one ray, [1] sum of their
+// spans in timer ticks, [2] earliest start, [3] latest end -- [3] - [2] over the launch's HIP-event time is the timer's rate,
+// [1] / ([0] ([3] - [2])) the share of the launch a working wave was resident for
+__device__ unsigned long long srt_wave_stats[4] = {0ull, 0ull, ~0ull, 0ull};
+#endif
 // Per-launch device scratch of a model (only the scattered model has any: srt_scattered.hpp overloads this).
 template <class M>
 __device__ __forceinline__ void bind_scratch(const M &, double *, double *, double * = nullptr) {}

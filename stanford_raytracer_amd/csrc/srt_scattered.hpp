@@ -533,10 +533,11 @@ struct ScatteredModel {
   //   [L + 64, L + 320) the 64 lanes' candidate-block headers {centre x, y, z, entry count (int; -1 = none)}
 #ifndef SRT_SCAT_WAVES
 // Waves per SIMD the cooperative kernels of this model are built for: 1 = 34.5 KiB of LDS per wave, all 512 registers, a ring of
-// four record buffers; 2 = 18.5 KiB, <= 256 registers, two buffers.  Measured at BASELINE config[4]'s full size, same box:
-// 21.6 s per launch with 1, 24.3 s with 2 (at 100 k rays they tie): with two waves the SIMD's clock drops by what their
-// interleaving gains (cycle counters: 1.17 against 1.63 GHz) -- the kernel is bound by power, i.e. by instructions executed.
-#define SRT_SCAT_WAVES 1
+// four record buffers; 2 = 18.5 KiB, <= 256 registers (every phase spill-free), two buffers.  Measured at BASELINE config[4]'s
+// full size, same box: 18.8 s per launch with 2, 20.1 s with 1.  (Before the staging buffer became chunk-major the second wave
+// bought nothing -- 24.3 s against 21.6 s: a CU's memory pipeline takes requests per cache LINE, and 16-byte pieces of 64
+// different records per instruction saturated it with four waves already.)
+#define SRT_SCAT_WAVES 2
 #endif
   static constexpr int WAVES_PER_EU = SRT_SCAT_WAVES;
   static constexpr int NBUF = WAVES_PER_EU == 2 ? 2 : 4;  // 64-record buffers of pass 2's ring
@@ -741,6 +742,12 @@ struct ScatteredModel {
   // Record: [0..2] x y z, [3..6] ln N_s, [7] -, after pass 1: [8] r_c [10] cos a_c [11] sin a_c; after the weights:
   // [8 + g] half-weight at point g (g < 7), [15] at the free point.
   static constexpr int REC = 16, REC_CAP = 4096;
+  // The staging buffer of a wave is chunk-major: 16-byte chunk t (0..7) of record k sits at (t * REC_CAP + k) * 16 bytes, so that
+  // the 64 lanes of a wave -- 64 consecutive records -- write and read 1 KiB of consecutive bytes per instruction (8 cache
+  // lines) instead of one 16-byte piece of 64 different lines: the memory pipeline of a CU takes requests per LINE.
+  __device__ __forceinline__ static SRT_AS1 d2_t *chunk(SRT_AS1 double *rec, int t, int k) {
+    return (SRT_AS1 d2_t *)rec + ((size_t)t * REC_CAP + (size_t)k);
+  }
 
   __device__ __forceinline__ double etainv_at(double ss, double hin) const { return etainv(sqrt(ss), hin); }
 
@@ -848,15 +855,14 @@ struct ScatteredModel {
           c8[7] += 1;
         }
       }
-      SRT_AS1 d2_t *r = (SRT_AS1 d2_t *)(rec + (size_t)k * REC);
-      r[0] = qa;
-      r[1] = qb;
-      r[2] = qc;
-      r[3] = d2_t{qd.x, 0.0};
+      *chunk(rec, 0, k) = qa;
+      *chunk(rec, 1, k) = qb;
+      *chunk(rec, 2, k) = qc;
+      *chunk(rec, 3, k) = d2_t{qd.x, 0.0};
       // (always, although only a list longer than the side arrays reads them back: a trip whose number of stores depends on
       // the path makes the compiler's wait for the next gather wait for these stores as well)
-      r[4] = d2_t{rc, 0.0};
-      r[5] = d2_t{ca, sa};
+      *chunk(rec, 4, k) = d2_t{rc, 0.0};
+      *chunk(rec, 5, k) = d2_t{ca, sa};
       if (k < side.cap) { // what the weights need waits in LDS
         side.a[k] = qa;
         side.b[k] = d2_t{q2, rc};
@@ -982,11 +988,10 @@ struct ScatteredModel {
       }
 #pragma unroll
       for (int gg = 0; gg < 8; ++gg) w8[gg] = (usemask && !(w8[gg] > 1.0e-16)) ? 0.0 : 0.5 * w8[gg]; // :316-317
-      SRT_AS1 d2_t *r = (SRT_AS1 d2_t *)(rec + (size_t)k * REC);
-      r[4] = d2_t{w8[0], w8[1]};
-      r[5] = d2_t{w8[2], w8[3]};
-      r[6] = d2_t{w8[4], w8[5]};
-      r[7] = d2_t{w8[6], w8[7]};
+      *chunk(rec, 4, k) = d2_t{w8[0], w8[1]};
+      *chunk(rec, 5, k) = d2_t{w8[2], w8[3]};
+      *chunk(rec, 6, k) = d2_t{w8[4], w8[5]};
+      *chunk(rec, 7, k) = d2_t{w8[6], w8[7]};
     };
     // the samples whose {x, y, z, r_c, cos, sin} wait in LDS: no load from device memory in this loop, so nothing in it ever
     // waits for the previous trip's stores
@@ -996,8 +1001,7 @@ struct ScatteredModel {
     // a list longer than the side arrays: the rest back from their records
 #pragma unroll 1
     for (int k = nlds + lane; k < n_list; k += 64) {
-      const SRT_AS1 d2_t *r = (const SRT_AS1 d2_t *)(rec + (size_t)k * REC);
-      const d2_t c0 = r[0], c1 = r[1], c4 = r[4], c5 = r[5];
+      const d2_t c0 = *chunk(rec, 0, k), c1 = *chunk(rec, 1, k), c4 = *chunk(rec, 4, k), c5 = *chunk(rec, 5, k);
       weigh(k, c0, d2_t{c1.x, c4.x}, c5);
     }
     __syncthreads(); // block == one wave: the weights written above are read by other lanes next
@@ -1070,11 +1074,10 @@ struct ScatteredModel {
       auto issue = [&](int c) {
         int r = c * 64 + lane;
         r = r < n_list ? r : n_list - 1;
-        const SRT_AS1 char *src = (const SRT_AS1 char *)(rec + (size_t)r * REC);
         SRT_AS3 char *dst = ring + (c % NBUF) * 8192;
 #pragma unroll
-        for (int t = 0; t < 8; ++t)
-          __builtin_amdgcn_global_load_lds((const SRT_AS1 void *)(src + 16 * t), (SRT_AS3 void *)(dst + 1024 * t), 16, 0, 0);
+        for (int t = 0; t < 8; ++t) // (chunk-major staging: instruction t reads 1 KiB of consecutive bytes)
+          __builtin_amdgcn_global_load_lds((const SRT_AS1 void *)chunk(rec, t, r), (SRT_AS3 void *)(dst + 1024 * t), 16, 0, 0);
       };
       const bool any = __any(fit);
       if (any) {
