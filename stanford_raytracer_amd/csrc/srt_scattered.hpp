@@ -859,14 +859,13 @@ struct ScatteredModel {
       *chunk(rec, 1, k) = qb;
       *chunk(rec, 2, k) = qc;
       *chunk(rec, 3, k) = d2_t{qd.x, 0.0};
-      // (always, although only a list longer than the side arrays reads them back: a trip whose number of stores depends on
-      // the path makes the compiler's wait for the next gather wait for these stores as well)
-      *chunk(rec, 4, k) = d2_t{rc, 0.0};
-      *chunk(rec, 5, k) = d2_t{ca, sa};
-      if (k < side.cap) { // what the weights need waits in LDS
+      if (k < side.cap) { // what the weights need waits in LDS ..
         side.a[k] = qa;
         side.b[k] = d2_t{q2, rc};
         side.c[k] = d2_t{ca, sa};
+      } else { // .. or, for a list longer than the side arrays, in the record
+        *chunk(rec, 4, k) = d2_t{rc, 0.0};
+        *chunk(rec, 5, k) = d2_t{ca, sa};
       }
     }
     SRT_PHASE(1);
@@ -1371,16 +1370,18 @@ struct ScatteredModel {
     return b;
   }
   // scan the 27 cells around the centre pc (all lanes) into `blk`; returns the entry count, -1 if the block cannot hold them
-  __device__ __forceinline__ int build_block(const double (&pc)[3], const Rows &Rc, SRT_AS1 f4_t *blk) const {
+  // (out of line: one stencil in twenty rebuilds its block; the nine rows' prefetch registers stay out of coop_stencil's allocation)
+  __device__ __noinline__ int build_block(const double (&pc)[3], const Rows &Rc, SRT_AS1 f4_t *blk) const {
+    const ScatteredModel M = uniform_copy();
     const int lane = threadIdx.x;
-    const double Rb = radius * (1.0 + bmargin), Rb2 = Rb * Rb;
+    const double Rb = M.radius * (1.0 + M.bmargin), Rb2 = Rb * Rb;
     int lo9[9], hi9[9], maxlen = 0;
 #pragma unroll
     for (int r = 0; r < 9; ++r) {
-      row_range(Rc, r, lo9[r], hi9[r]);
+      M.row_range(Rc, r, lo9[r], hi9[r]);
       maxlen = max(maxlen, hi9[r] - lo9[r]);
     }
-    const SRT_AS1 double *xs = gxyz(), *ys = xs + npts, *zs = ys + npts;
+    const SRT_AS1 double *xs = M.gxyz(), *ys = xs + M.npts, *zs = ys + M.npts;
     int idxn[9];
     double qxn[9], qyn[9], qzn[9];
     auto fetch = [&](int t0) {
@@ -1441,6 +1442,57 @@ struct ScatteredModel {
         n_list = __builtin_amdgcn_readfirstlane(n_list + __popcll(m));
       }
     }
+    return n_list;
+  }
+
+  // Candidates of a stencil centred at pc by a scan of the centre's 27 cells (all lanes; rs = radius widened by the largest
+  // distance of a stencil point from the centre: a superset of every point's neighbour set, each point applies its own exact
+  // test later).  All nine candidate rows advance together, 64 samples of each per trip: 27 coalesced loads in flight at once, no
+  // index arithmetic beyond row start + lane.  List order: trip, row, lane.  Returns the list length, -1 if the list would not
+  // fit the list area or the staging buffer (a trip adds at most TRIP_MAX entries: tested once per trip).
+  __device__ __noinline__ int scan_cells(const double (&pc)[3], double rs, const Rows &Rc, SRT_LDS int *lists) const {
+    const ScatteredModel M = uniform_copy();
+    const int lane = threadIdx.x;
+    const double rs2 = rs * rs * (1.0 + 1.0e-12);
+    int lo9[9], hi9[9], maxlen = 0;
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+      M.row_range(Rc, r, lo9[r], hi9[r]);
+      maxlen = max(maxlen, hi9[r] - lo9[r]);
+    }
+    const SRT_AS1 double *xs = M.gxyz(), *ys = xs + M.npts, *zs = ys + M.npts;
+    // (one trip ahead: the next 27 loads are in flight while this trip's samples are tested and compacted)
+    int idxn[9];
+    double qxn[9], qyn[9], qzn[9];
+    auto fetch = [&](int t0) {
+#pragma unroll
+      for (int r = 0; r < 9; ++r) {
+        const int i = lo9[r] + t0 + lane;
+        idxn[r] = i < hi9[r] ? i : -1;
+        const int ic = idxn[r] < 0 ? 0 : idxn[r];
+        qxn[r] = xs[ic], qyn[r] = ys[ic], qzn[r] = zs[ic];
+      }
+    };
+    int n_list = 0;
+    if (maxlen > 0) fetch(0);
+#pragma unroll 1
+    for (int t0 = 0; t0 < maxlen; t0 += 64) {
+      if (n_list > (SHARED_CAP < REC_CAP ? SHARED_CAP : REC_CAP) - TRIP_MAX) return -1;
+      int idx[9];
+      double qx[9], qy[9], qz[9];
+#pragma unroll
+      for (int r = 0; r < 9; ++r) idx[r] = idxn[r], qx[r] = qxn[r], qy[r] = qyn[r], qz[r] = qzn[r];
+      if (t0 + 64 < maxlen) fetch(t0 + 64);
+#pragma unroll
+      for (int r = 0; r < 9; ++r) {
+        const double d0 = qx[r] - pc[0], d1 = qy[r] - pc[1], d2 = qz[r] - pc[2];
+        const bool acc = idx[r] >= 0 && d0 * d0 + d1 * d1 + d2 * d2 < rs2;
+        const unsigned long long m = __ballot(acc);
+        if (acc) lists[n_list + __popcll(m & ((1ull << lane) - 1ull))] = idx[r];
+        n_list = __builtin_amdgcn_readfirstlane(n_list + __popcll(m));
+      }
+    }
+    __syncthreads(); // block == one wave: orders the list writes before the reads of the caller
     return n_list;
   }
 
@@ -1560,62 +1612,16 @@ struct ScatteredModel {
       }
       if (!shared && geom &&
           !__any(g < npts && (cx != __shfl(cx, 0) || R.cy != __shfl(R.cy, 0) || R.cz != __shfl(R.cz, 0)))) {
-        shared = true;
-        // widen by the largest distance of a stencil point from the centre (plus rounding slack): a superset of
-        // every point's neighbour set; each point applies its own exact test later
-        const double rs = radius + ext;
-        const double rs2 = rs * rs * (1.0 + 1.0e-12);
+        // ---- no block (layered kernels; block overflow): scan the centre's 27 cells
         Rows Rc;
         Rc.cy = __builtin_amdgcn_readlane(R.cy, 0);
         Rc.cz = __builtin_amdgcn_readlane(R.cz, 0);
         Rc.x0 = __builtin_amdgcn_readlane(R.x0, 0);
         Rc.x1 = __builtin_amdgcn_readlane(R.x1, 0);
         Rc.live = true;
-        // All nine candidate rows advance together, 64 samples of each per trip: 27 coalesced loads in flight at once, no
-        // index arithmetic beyond row start + lane.  List order: trip, row, lane.  The list area holds SHARED_CAP entries
-        // and a trip adds at most TRIP_MAX, so the overflow test is made once per trip.
-        int lo9[9], hi9[9], maxlen = 0;
-#pragma unroll
-        for (int r = 0; r < 9; ++r) {
-          M.row_range(Rc, r, lo9[r], hi9[r]);
-          maxlen = max(maxlen, hi9[r] - lo9[r]);
-        }
-        SRT_PHASE_ADD(11, hi9[0] - lo9[0] + hi9[1] - lo9[1] + hi9[2] - lo9[2] + hi9[3] - lo9[3] + hi9[4] - lo9[4] + hi9[5] - lo9[5] + hi9[6] - lo9[6] + hi9[7] - lo9[7] + hi9[8] - lo9[8]);
-        const SRT_AS1 double *xs = M.gxyz(), *ys = xs + M.npts, *zs = ys + M.npts;
-        // (one trip ahead: the next 27 loads are in flight while this trip's samples are tested and compacted)
-        int idxn[9];
-        double qxn[9], qyn[9], qzn[9];
-        auto fetch = [&](int t0) {
-#pragma unroll
-          for (int r = 0; r < 9; ++r) {
-            const int i = lo9[r] + t0 + lane;
-            idxn[r] = i < hi9[r] ? i : -1;
-            const int ic = idxn[r] < 0 ? 0 : idxn[r];
-            qxn[r] = xs[ic], qyn[r] = ys[ic], qzn[r] = zs[ic];
-          }
-        };
-        if (maxlen > 0) fetch(0);
-#pragma unroll 1
-        for (int t0 = 0; t0 < maxlen; t0 += 64) {
-          if (n_list > (SHARED_CAP < REC_CAP ? SHARED_CAP : REC_CAP) - TRIP_MAX) { // would not fit (list area, staging buffer): every group scans for itself instead
-            shared = false;
-            break;
-          }
-          int idx[9];
-          double qx[9], qy[9], qz[9];
-#pragma unroll
-          for (int r = 0; r < 9; ++r) idx[r] = idxn[r], qx[r] = qxn[r], qy[r] = qyn[r], qz[r] = qzn[r];
-          if (t0 + 64 < maxlen) fetch(t0 + 64);
-#pragma unroll
-          for (int r = 0; r < 9; ++r) {
-            const double d0 = qx[r] - pc[0], d1 = qy[r] - pc[1], d2 = qz[r] - pc[2];
-            const bool acc = idx[r] >= 0 && d0 * d0 + d1 * d1 + d2 * d2 < rs2;
-            const unsigned long long m = __ballot(acc);
-            if (acc) lists[n_list + __popcll(m & ((1ull << lane) - 1ull))] = idx[r];
-            n_list = __builtin_amdgcn_readfirstlane(n_list + __popcll(m));
-          }
-        }
-        __syncthreads(); // block == one wave: orders the list writes before the reads below
+        n_list = M.scan_cells(pc, radius + ext, Rc, lists);
+        shared = n_list >= 0; // (-1: would not fit the list area / the staging buffer: every group scans for itself instead)
+        n_list = shared ? n_list : 0;
       }
       SRT_PHASE(0);
       SRT_PHASE_ADD(10, n_list);
