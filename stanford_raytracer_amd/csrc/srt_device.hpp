@@ -85,6 +85,7 @@ constexpr bool field_igrf_only() { return std::is_same<CM, CommonIgrfOnly>::valu
 //  * One point per call is a 105-step chain of dependent fp32 operations with one wave per SIMD to hide it behind:
 //    the seven stencil points of a right-hand side are therefore synthesised together (independent chains).
 //  * The Fortran's A(N), B(N) arrays are the running products r^-(n+1), n r^-(n+1): registers, same multiplication chain.
+typedef float f2_t __attribute__((ext_vector_type(2)));
 template <int NP>
 __device__ __forceinline__ void igrf_core(const FieldConst &f, const float (&xg)[NP], const float (&yg)[NP], const float (&zg)[NP],
                                           float (&hx)[NP], float (&hy)[NP], float (&hz)[NP]) {
@@ -127,64 +128,134 @@ __device__ __forceinline__ void igrf_core(const FieldConst &f, const float (&xg)
     kmax = o > kmax ? o : kmax;
   }
   kmax = __builtin_amdgcn_readfirstlane(kmax);
+#ifdef SRT_IGRF_PROBE_KMAX
+  kmax = kmax < SRT_IGRF_PROBE_KMAX ? kmax : SRT_IGRF_PROBE_KMAX; // (timing probe only: wrong fields)
+#endif
   // The points of one stencil lie within 1e-6 of each other: they share the truncation degree unless r + 2 crosses an
   // integer between them.  Then ONE predicate per lane and trip covers all NP chains (the per-point form below costs
   // an exec-mask save/restore per point and trip).
   bool samek = true;
 #pragma unroll
   for (int i = 1; i < NP; ++i) samek = samek && k[i] == k[0];
-  if (NP > 1 && __all(samek)) {
+  bool paired = false;
+  if constexpr (NP > 2) if (__all(samek)) {
+    paired = true;
+    // Two points per register pair: every multiplication and addition below is one v_pk_mul_f32 / v_pk_add_f32 for two
+    // chains (IEEE operations, unfused as in the Fortran: the same bits as the one-point form, half the instructions).
+    // An odd NP repeats its last point in the spare half.  The n loop is unrolled twice with the roles of (q, z) and
+    // (p2, d2) exchanged, so the recurrence's hand-down costs no register moves.
+    constexpr int NQ = (NP + 1) / 2;
     const int kl = k[0];
+    f2_t C[NQ], S[NQ], CF[NQ], SF[NQ], PP[NQ], P[NQ], D[NQ], BR[NQ], BT[NQ], BF[NQ], X[NQ], Y[NQ], AM[NQ];
+    bool pa[NQ], pb[NQ], polar = false;
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+      const int a = 2 * j, b = 2 * j + 1 < NP ? 2 * j + 1 : NP - 1;
+      C[j] = f2_t{c[a], c[b]};
+      S[j] = f2_t{s[a], s[b]};
+      CF[j] = f2_t{cf[a], cf[b]};
+      SF[j] = f2_t{sf[a], sf[b]};
+      PP[j] = f2_t{pp[a], pp[b]};
+      pa[j] = pole[a];
+      pb[j] = pole[b];
+      polar = polar || pa[j] || pb[j];
+      P[j] = Y[j] = f2_t{1.f, 1.f};
+      D[j] = BR[j] = BT[j] = BF[j] = X[j] = f2_t{0.f, 0.f};
+      AM[j] = PP[j] * PP[j];
+    }
+    const bool anypole = __any(polar); // wave-uniform
     for (int m = 1; m <= kmax; ++m) {
-      float q[NP], z[NP], bi[NP], p2[NP], d2[NP], an[NP];
+      f2_t Q[NQ], Z[NQ], BI[NQ], BIZ[NQ], P2[NQ], D2[NQ], AN[NQ];
       const bool mlive = m <= kl;
 #pragma unroll
-      for (int i = 0; i < NP; ++i) {
+      for (int j = 0; j < NQ; ++j) {
         if (mlive && m > 1) {
-          const float w = x[i];
-          x[i] = w * cf[i] + y[i] * sf[i];
-          y[i] = y[i] * cf[i] - w * sf[i];
+          const f2_t w = X[j];
+          X[j] = w * CF[j] + Y[j] * SF[j];
+          Y[j] = Y[j] * CF[j] - w * SF[j];
         }
-        q[i] = p[i];
-        z[i] = d[i];
-        bi[i] = p2[i] = d2[i] = 0.f;
-        an[i] = am[i];
+        Q[j] = P[j];
+        Z[j] = D[j];
+        BI[j] = BIZ[j] = P2[j] = D2[j] = f2_t{0.f, 0.f};
+        AN[j] = AM[j];
       }
       const int base = igrf_off(m) - m;
-      for (int n = m; n <= kmax; ++n) {
-        const int t = base + n, j = t & 63; // wave-uniform
-        const float e = __builtin_bit_cast(float, t >= 64 ? __builtin_amdgcn_readlane(g1, j) : __builtin_amdgcn_readlane(g0, j));
-        const float hh = __builtin_bit_cast(float, t >= 64 ? __builtin_amdgcn_readlane(h1, j) : __builtin_amdgcn_readlane(h0, j));
-        const float xk = __builtin_bit_cast(float, t >= 64 ? __builtin_amdgcn_readlane(r1, j) : __builtin_amdgcn_readlane(r0, j));
+      // one (m, n) term for all chains; the new (q, z) are left in (p2, d2) and the old (q, z) are the next (p2, d2)
+      auto term = [&](int n, f2_t (&q)[NQ], f2_t (&z)[NQ], f2_t (&p2)[NQ], f2_t (&d2)[NQ]) {
+#pragma clang fp contract(off)
+        const int t = base + n, j6 = t & 63; // wave-uniform
+        const int eg0 = __builtin_amdgcn_readlane(g0, j6), eg1 = __builtin_amdgcn_readlane(g1, j6);
+        const int eh0 = __builtin_amdgcn_readlane(h0, j6), eh1 = __builtin_amdgcn_readlane(h1, j6);
+        const int er0 = __builtin_amdgcn_readlane(r0, j6), er1 = __builtin_amdgcn_readlane(r1, j6);
+        const float e = __builtin_bit_cast(float, t >= 64 ? eg1 : eg0), hh = __builtin_bit_cast(float, t >= 64 ? eh1 : eh0);
+        const float xk = __builtin_bit_cast(float, t >= 64 ? er1 : er0);
         const float fn = (float)n;
         if (n <= kl) {
-#pragma unroll
-          for (int i = 0; i < NP; ++i) {
-            const float w = e * y[i] + hh * x[i];
-            bbr[i] = bbr[i] + (an[i] * fn) * w * q[i];
-            bbt[i] = bbt[i] - an[i] * w * z[i];
-            if (m != 1) bi[i] = bi[i] + an[i] * (e * x[i] - hh * y[i]) * (pole[i] ? z[i] : q[i]);
-            const float dp = c[i] * z[i] - s[i] * q[i] - xk * d2[i];
-            const float pm = c[i] * q[i] - xk * p2[i];
-            d2[i] = z[i];
-            p2[i] = q[i];
-            z[i] = dp;
-            q[i] = pm;
-            an[i] = an[i] * pp[i];
+          // Written row by row over the chains, each row's results passed through an empty volatile asm (no instruction;
+          // it pins the order: the row's operations come before it, their consumers after).  A packed operation issued
+          // right behind its producer waits ~11 cycles instead of 4 and needs a wait state, and left to itself the
+          // scheduler puts a chain's operations next to each other -- with one wave per SIMD there is nothing else to
+          // issue meanwhile.
+          f2_t t1[NQ], t2[NQ], w[NQ], u[NQ];
+#define IGRF_ROW_(dst, expr)                                                                                           \
+  _Pragma("unroll") for (int j = 0; j < NQ; ++j) dst[j] = expr;                                                        \
+  _Pragma("unroll") for (int j = 0; j < NQ; ++j) asm volatile("" : "+v"(dst[j]))
+          IGRF_ROW_(t1, e * Y[j]);
+          IGRF_ROW_(t2, hh * X[j]);
+          IGRF_ROW_(w, t1[j] + t2[j]);
+          IGRF_ROW_(u, AN[j] * fn);
+          IGRF_ROW_(u, u[j] * w[j]);
+          IGRF_ROW_(u, u[j] * q[j]);
+          IGRF_ROW_(BR, BR[j] + u[j]);
+          IGRF_ROW_(u, AN[j] * w[j]);
+          IGRF_ROW_(u, u[j] * z[j]);
+          IGRF_ROW_(BT, BT[j] - u[j]);
+          if (m != 1) {
+            IGRF_ROW_(t1, e * X[j]);
+            IGRF_ROW_(t2, hh * Y[j]);
+            IGRF_ROW_(w, t1[j] - t2[j]);
+            IGRF_ROW_(w, AN[j] * w[j]);
+            IGRF_ROW_(u, w[j] * q[j]);
+            IGRF_ROW_(BI, BI[j] + u[j]);
+            if (anypole) { // (a lane on the polar axis sums with z in place of q: the sum it will pick at the end of this m)
+              IGRF_ROW_(u, w[j] * z[j]);
+              IGRF_ROW_(BIZ, BIZ[j] + u[j]);
+            }
           }
+          IGRF_ROW_(t1, C[j] * z[j]);
+          IGRF_ROW_(t2, S[j] * q[j]);
+          IGRF_ROW_(w, t1[j] - t2[j]);
+          IGRF_ROW_(t1, xk * d2[j]);
+          IGRF_ROW_(d2, w[j] - t1[j]);
+          IGRF_ROW_(t1, C[j] * q[j]);
+          IGRF_ROW_(t2, xk * p2[j]);
+          IGRF_ROW_(p2, t1[j] - t2[j]);
+          IGRF_ROW_(AN, AN[j] * PP[j]);
+#undef IGRF_ROW_
         }
+      };
+      for (int n = m; n <= kmax; n += 2) {
+        term(n, Q, Z, P2, D2);
+        if (n + 1 <= kmax) term(n + 1, P2, D2, Q, Z);
       }
       if (mlive) {
 #pragma unroll
-        for (int i = 0; i < NP; ++i) {
-          d[i] = s[i] * d[i] + c[i] * p[i];
-          p[i] = s[i] * p[i];
-          if (m != 1) bbf[i] = bbf[i] + bi[i] * (float)(m - 1);
-          am[i] = am[i] * pp[i];
+        for (int j = 0; j < NQ; ++j) {
+          D[j] = S[j] * D[j] + C[j] * P[j];
+          P[j] = S[j] * P[j];
+          if (m != 1) BF[j] = BF[j] + f2_t{pa[j] ? BIZ[j].x : BI[j].x, pb[j] ? BIZ[j].y : BI[j].y} * (float)(m - 1);
+          AM[j] = AM[j] * PP[j];
         }
       }
     }
-  } else
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      bbr[i] = (i & 1) ? BR[i / 2].y : BR[i / 2].x;
+      bbt[i] = (i & 1) ? BT[i / 2].y : BT[i / 2].x;
+      bbf[i] = (i & 1) ? BF[i / 2].y : BF[i / 2].x;
+    }
+  }
+  if (!paired)
   for (int m = 1; m <= kmax; ++m) {
     float q[NP], z[NP], bi[NP], p2[NP], d2[NP], an[NP];
 #pragma unroll
