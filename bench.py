@@ -705,6 +705,11 @@ def other_config_line(ctx, res, pmc):
                        "valu_busy": pmc["SQ_ACTIVE_INST_VALU"] / max(pmc["SQ_WAVE_CYCLES"], 1.0),
                        "wave_instructions": {k: pmc[k] for k in pmc if k.startswith("SQ_INSTS_VALU_")},
                        "source": "live: rocprofv3 --pmc child pass of one launch of this workload"})
+            if tuple(res.get("field", (0, 0)))[0]:
+                # the IGRF synthesis runs on v_pk_mul_f32 / v_pk_add_f32 (two operations per lane and instruction); the
+                # counters count such an instruction once, so fp32 "achieved" at 64 operations per instruction is a floor
+                rf["fp32_note"] = ("the IGRF synthesis issues packed fp32 instructions (2 operations per lane); SQ_INSTS_VALU_*_F32 "
+                                   "counts each once: achieved.fp32 is a lower bound, up to 2x")
         elif pmc:
             rf["source"] = "unavailable: %s" % pmc["error"]
         line["roofline"] = rf
