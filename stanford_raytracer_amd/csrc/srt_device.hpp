@@ -39,7 +39,8 @@ struct FieldConst {
   // recursion constants and the GEO->GSM matrix, as RECALC_08 leaves them (host: srt_host::igrf_setup)
   int use_igrf, yearday, msec, use_tsy;
   // g, h, rec per (m, n) term in the ORDER THE SYNTHESIS VISITS THEM (m = 1..14 outer, n = m..14 inner): entry
-  // (m, n) sits at igrf_off(m) + n - m.  Padded to 128: lane l of a wave keeps entries l and l + 64 in registers.
+  // (m, n) sits at igrf_off(m) + n - m (rows 1..5 in 0..59, rows 6..14 from 64).  128 entries: lane l of a wave keeps entries l
+  // and l + 64 in registers.
   float Gv[128], Hv[128], Rv[128];
   float A[9];
   // use_tsyganenko = 1 (interp_dens_model_adapter.f95:223-258): T04_s(iopt, real(parmod), real(psi), real(x_gsm/R_E));
@@ -47,7 +48,8 @@ struct FieldConst {
   // which aliases geopack's ST0 (see srt_host::igrf_setup)
   float parmod[10], psi;
 };
-__host__ __device__ inline int igrf_off(int m) { return (m - 1) * 15 - (m - 1) * m / 2; }
+// (rows m >= 6 start at 64: no row straddles the two register halves, so the half is chosen once per m, not per term)
+__host__ __device__ inline int igrf_off(int m) { return (m - 1) * 15 - (m - 1) * m / 2 + (m >= 6 ? 4 : 0); }
 
 struct Common {
   Species sp;
@@ -180,15 +182,14 @@ __device__ __forceinline__ void igrf_core(const FieldConst &f, const float (&xg)
         AN[j] = AM[j];
       }
       const int base = igrf_off(m) - m;
+      const int gm = m >= 6 ? g1 : g0, hm = m >= 6 ? h1 : h0, rm = m >= 6 ? r1 : r0; // the row's half of the table
       // one (m, n) term for all chains; the new (q, z) are left in (p2, d2) and the old (q, z) are the next (p2, d2)
       auto term = [&](int n, f2_t (&q)[NQ], f2_t (&z)[NQ], f2_t (&p2)[NQ], f2_t (&d2)[NQ]) {
 #pragma clang fp contract(off)
-        const int t = base + n, j6 = t & 63; // wave-uniform
-        const int eg0 = __builtin_amdgcn_readlane(g0, j6), eg1 = __builtin_amdgcn_readlane(g1, j6);
-        const int eh0 = __builtin_amdgcn_readlane(h0, j6), eh1 = __builtin_amdgcn_readlane(h1, j6);
-        const int er0 = __builtin_amdgcn_readlane(r0, j6), er1 = __builtin_amdgcn_readlane(r1, j6);
-        const float e = __builtin_bit_cast(float, t >= 64 ? eg1 : eg0), hh = __builtin_bit_cast(float, t >= 64 ? eh1 : eh0);
-        const float xk = __builtin_bit_cast(float, t >= 64 ? er1 : er0);
+        const int j6 = (base + n) & 63; // wave-uniform
+        const float e = __builtin_bit_cast(float, __builtin_amdgcn_readlane(gm, j6));
+        const float hh = __builtin_bit_cast(float, __builtin_amdgcn_readlane(hm, j6));
+        const float xk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(rm, j6));
         const float fn = (float)n;
         if (n <= kl) {
           // Written row by row over the chains, each row's results passed through an empty volatile asm (no instruction;
@@ -271,11 +272,12 @@ __device__ __forceinline__ void igrf_core(const FieldConst &f, const float (&xg)
       an[i] = am[i];
     }
     const int base = igrf_off(m) - m;
+    const int gm = m >= 6 ? g1 : g0, hm = m >= 6 ? h1 : h0, rm = m >= 6 ? r1 : r0;
     for (int n = m; n <= kmax; ++n) {
-      const int t = base + n, j = t & 63; // wave-uniform
-      const float e = __builtin_bit_cast(float, t >= 64 ? __builtin_amdgcn_readlane(g1, j) : __builtin_amdgcn_readlane(g0, j));
-      const float hh = __builtin_bit_cast(float, t >= 64 ? __builtin_amdgcn_readlane(h1, j) : __builtin_amdgcn_readlane(h0, j));
-      const float xk = __builtin_bit_cast(float, t >= 64 ? __builtin_amdgcn_readlane(r1, j) : __builtin_amdgcn_readlane(r0, j));
+      const int j = (base + n) & 63; // wave-uniform
+      const float e = __builtin_bit_cast(float, __builtin_amdgcn_readlane(gm, j));
+      const float hh = __builtin_bit_cast(float, __builtin_amdgcn_readlane(hm, j));
+      const float xk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(rm, j));
       const float fn = (float)n;
 #pragma unroll
       for (int i = 0; i < NP; ++i) {

@@ -859,6 +859,14 @@ struct ScatteredModel {
       *chunk(rec, 1, k) = qb;
       *chunk(rec, 2, k) = qc;
       *chunk(rec, 3, k) = d2_t{qd.x, 0.0};
+#ifdef SRT_PROBE_EXTRA_STORES // (timing probe: the same 64 bytes once more, into chunks the weights overwrite later)
+      *chunk(rec, 6, k) = qa;
+      *chunk(rec, 7, k) = qb;
+      if (k < side.cap) {
+        *chunk(rec, 4, k) = qc;
+        *chunk(rec, 5, k) = qd;
+      }
+#endif
       if (k < side.cap) { // what the weights need waits in LDS ..
         side.a[k] = qa;
         side.b[k] = d2_t{q2, rc};
@@ -1204,23 +1212,17 @@ struct ScatteredModel {
     sf_weights<J>(p, live, livemask, npts, n_list, list, rec, dmax6, d7, p7near, true);
     return live && pass1_out(list)->cnt8[threadIdx.x >> 3] >= J;
   }
-  template <int J>
-  __device__ __noinline__ void sf_reweigh(const double (&p)[3], bool live, unsigned long long livemask, int npts, int n_list,
-                                          SRT_LDS const int *list, double *rec, double dmax6, double d7, bool p7near) const {
-    sf_weights<J>(p, live, livemask, npts, n_list, list, rec, dmax6, d7, p7near, false);
-  }
+  // `redo`: some point threw out too many samples (fewer than J kept: "use them all", lsinterp_mod.f95:319-323).  The list, the
+  // side arrays and pass 1's results are gone by then (the pair loop's ring and the parked totals have overwritten them), so
+  // the caller serves this stencil on the own-list path, which carries that rule itself (wave-uniform; rare).
   template <int J>
   __device__ __forceinline__ Fit4 shared_fit(const double (&p)[3], bool live, unsigned long long livemask, int npts, int n_list,
-                                             SRT_LDS const int *list, double *rec, double dmax6, double d7, bool p7near) const {
+                                             SRT_LDS const int *list, double *rec, double dmax6, double d7, bool p7near,
+                                             bool &redo) const {
     const bool fit = sf_prepare<J>(p, live, livemask, npts, n_list, list, rec, dmax6, d7, p7near);
     int kept = 0;
-    Fit4 fi = sf_sums<J>(p, fit, n_list, list, rec, kept);
-    const bool again = fit && kept < J; // threw out too many samples: use them all (:319-323)
-    if (__any(again)) {                 // (wave-uniform; rare)
-      sf_reweigh<J>(p, live, livemask, npts, n_list, list, rec, dmax6, d7, p7near);
-      const Fit4 f2 = sf_sums<J>(p, again, n_list, list, rec, kept);
-      if (again) fi = f2;
-    }
+    const Fit4 fi = sf_sums<J>(p, fit, n_list, list, rec, kept);
+    redo = __any(fit && kept < J);
     return fi;
   }
   // The own-list path: the stencil straddles a grid cell, is too wide for the series, or the shared list would not
@@ -1625,8 +1627,13 @@ struct ScatteredModel {
       }
       SRT_PHASE(0);
       SRT_PHASE_ADD(10, n_list);
-      const Fit4 fi = shared ? shared_fit<J>(p, live, livemask, npts, n_list, lists, rec, dmax, d7, p7near)
-                             : own_fit<J>(p, live, R, lists);
+      Fit4 fi;
+      bool own = !shared;
+      if (shared) fi = shared_fit<J>(p, live, livemask, npts, n_list, lists, rec, dmax, d7, p7near, own);
+      if (own) {
+        __syncthreads(); // (after a shared attempt: its LDS traffic is over before the lists are rebuilt)
+        fi = own_fit<J>(p, live, R, lists);
+      }
       SRT_PHASE(shared ? 9 : 7);
       // hand the results to the owner through LDS (behind the lists and the buffer pointers): the group leaders
       // park their four densities, the owner collects the 8 x 4

@@ -215,3 +215,51 @@ def test_orders_0_and_1_through_both_paths(pointsfile, order):
     for other in (b, og):
         e = vrel(a[:, 4:7], other[:, 4:7])
         assert np.median(e) <= 1e-5 and np.percentile(e, 90) <= 1e-3
+
+
+def test_too_few_samples_above_the_weight_mask_goes_through_the_own_list_rule(tmp_path):
+    """lsinterp_mod.f95:316-323: weights <= 1e-16 are masked, and a point that keeps fewer than J samples "uses them all".
+    Query points in a void next to a densely sampled ball: >= J samples inside the search radius (which the sparsest sample of
+    the set makes large), every one of them tens of local window widths away, so every weight is below the mask.  The shared
+    path cannot redo its weights (its list and side arrays are gone by the time the count is known): it must hand the stencil
+    to the own-list path, which carries the rule -- the two runs are then the same arithmetic, bit for bit -- and the
+    answers are the oracle's."""
+    from oracle import oracle
+    from stanford_raytracer_amd import api, workloads as wl
+
+    g0 = np.load(os.path.join(GOLDEN_DIR, "points5500.npz"))
+    h0 = 3.0e4                                         # lattice spacing inside the ball
+    c0 = np.array([3.2 * wl.R_E, 0.4 * wl.R_E, 0.3 * wl.R_E])
+    ax = np.arange(-6, 7) * h0
+    L = np.stack(np.meshgrid(ax, ax, ax, indexing="ij"), -1).reshape(-1, 3)
+    L = L[np.linalg.norm(L, axis=1) <= 6.2 * h0]
+    rng = np.random.default_rng(5)
+    ball = c0 + L + rng.uniform(-0.05, 0.05, L.shape) * h0
+    lone = np.array([[-4.0 * wl.R_E, 0.1 * wl.R_E, 0.2 * wl.R_E], [-4.0 * wl.R_E + 2.0e6, 0.1 * wl.R_E, 0.2 * wl.R_E]])
+    pts = np.concatenate([ball, lone])                 # the pair's 2 000 km spacing sets the search radius: 3 000 km
+    s = (pts - c0) / wl.R_E
+    base = np.array([13.5, 13.4, 11.0, 9.6])
+    lnN = base + s @ np.array([[-2.0, -2.0, -1.5, -1.0], [0.3, 0.3, 0.2, 0.1], [-0.2, -0.2, -0.1, -0.1]]) \
+        + 0.5 * (s[:, :1] ** 2) * np.array([0.4, 0.4, 0.3, 0.2])
+    path = str(tmp_path / "void.txt")
+    wl.write_points_file(path, pts, lnN, g0["bounds"], g0["qs"], g0["ms"])
+    g = api.Model.scattered_file(path)
+    o = oracle.Model.scattered_file(path, perm_seed=2 | 0x80000000)
+    # query points 1 100 - 1 700 km outside the ball's surface: h = local_window_scale (5) x the 30 km spacing, so
+    # r / (h/4) > 29 for every sample and every weight is below 2e-18
+    u = rng.normal(size=(64, 3))
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    x = c0 + u * (6.2 * h0 + rng.uniform(1.1e6, 1.7e6, (64, 1)))
+    x = x[np.linalg.norm(x, axis=1) > 1.5 * wl.R_E]
+    _, d, w = wl.launch_set(len(x), 12)
+    od = np.array([o.disp(p, dd, ww) for p, dd, ww in zip(x, d, w)])
+    ok = od[:, 8] > 0
+    x, k, w = x[ok], od[ok, 8:9] * d[ok], w[ok]
+    assert len(x) >= 16
+    a = g.gradients(x, k, w, 1e-6)
+    b = _own_list(lambda: g.gradients(x, k, w, 1e-6))
+    og = np.array([o.grad(p, kk, ww, 1e-6) for p, kk, ww in zip(x, k, w)])
+    assert np.isfinite(a).all() and np.isfinite(og).all()
+    assert np.array_equal(a, b)                        # both runs end in own_fit: identical arithmetic
+    assert vrel(a[:, 0:3], og[:, 0:3]).max() <= 1e-5   # dF/dk: the densities at the centre (an extrapolation over 1 000 km from a
+                                                       # 190 km ball: the fit itself is good to 1e-7; measured 9e-7)
