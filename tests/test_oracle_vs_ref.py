@@ -100,3 +100,48 @@ def test_oracle_reproduces_the_drivers_adaptive_file(oracle_models):
         assert len(kept) == len(r) and np.all(r[:, 1] == stop[ray])
         assert np.allclose(kept[:, 0:16], r[:, 2:18], rtol=2e-15, atol=0)     # t, pos, vprel, vgrel, n, B0
         assert np.allclose(kept[:, 16:20], r[:, 28:32], rtol=2e-15, atol=0)   # Ns
+
+
+def test_scattered_weight_mask_exception_against_the_reference(tmp_path):
+    """lsinterp_mod.f95:316-323 on the reference itself: query points in a void next to a densely sampled ball keep NO
+    sample above the 1e-16 weight mask, so the reference "uses them all".  The oracle's restatement of that rule gives the
+    reference's densities (the same scenario drives the HIP path in
+    tests/test_gpu_scattered_paths.py::test_too_few_samples_above_the_weight_mask_goes_through_the_own_list_rule)."""
+    import os
+
+    from conftest import GOLDEN_DIR
+    from oracle import oracle
+
+    g0 = np.load(os.path.join(GOLDEN_DIR, "points5500.npz"))
+    h0 = 3.0e4
+    c0 = np.array([3.2 * wl.R_E, 0.4 * wl.R_E, 0.3 * wl.R_E])
+    ax = np.arange(-6, 7) * h0
+    L = np.stack(np.meshgrid(ax, ax, ax, indexing="ij"), -1).reshape(-1, 3)
+    L = L[np.linalg.norm(L, axis=1) <= 6.2 * h0]
+    rng = np.random.default_rng(5)
+    ball = c0 + L + rng.uniform(-0.05, 0.05, L.shape) * h0
+    lone = np.array([[-4.0 * wl.R_E, 0.1 * wl.R_E, 0.2 * wl.R_E], [-4.0 * wl.R_E + 2.0e6, 0.1 * wl.R_E, 0.2 * wl.R_E]])
+    pts = np.concatenate([ball, lone])
+    s = (pts - c0) / wl.R_E
+    lnN = np.array([13.5, 13.4, 11.0, 9.6]) + s @ np.array([[-2.0, -2.0, -1.5, -1.0], [0.3, 0.3, 0.2, 0.1], [-0.2, -0.2, -0.1, -0.1]]) \
+        + 0.5 * (s[:, :1] ** 2) * np.array([0.4, 0.4, 0.3, 0.2])
+    path = str(tmp_path / "void.txt")
+    wl.write_points_file(path, pts, lnN, g0["bounds"], g0["qs"], g0["ms"])
+    mdl = {"kind": 4, "file": path}
+    u = rng.normal(size=(64, 3))
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    x = c0 + u * (6.2 * h0 + rng.uniform(1.1e6, 1.7e6, (64, 1)))
+    x = x[np.linalg.norm(x, axis=1) > 1.5 * wl.R_E]
+    # every weight of every query point is below the mask (h = 5 x the 30 km spacing; r / (h/4) > 29)
+    r = np.linalg.norm(ball[None, :, :] - x[:, None, :], axis=2)
+    assert (r < 3.0e6).sum(axis=1).min() >= 10 and np.exp(-(r.min() / (5.0 * h0 * 1.06 / 4.0)) ** 1.1) < 1e-16
+    ref = refharness.run_mode("params", x, mdl)
+    root, _, _ = refharness.scattered_root(mdl)
+    m = oracle.Model.scattered_file(path, perm_seed=2)
+    m.set_spacing(root, 0.0)   # the reference's tree root keeps spacing 0 (SURVEY A-12)
+    mine = np.array([np.concatenate(m.plasma_params(p)) for p in x])
+    assert np.isfinite(ref).all() and (ref[:, 4:8] > 0).all()
+    # the fit extrapolates over 1 000 km from a 190 km ball: condition ~1e9, the summation order differs (A-12)
+    assert np.allclose(mine[:, 4:8], ref[:, 4:8], rtol=1e-5, atol=0)
+    # and it is the rule that matters: without it (all weights masked) the reference would return exp(0) = 1
+    assert (np.abs(np.log(ref[:, 4])) > 5).all()
