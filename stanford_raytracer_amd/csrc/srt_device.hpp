@@ -136,9 +136,11 @@ __device__ __forceinline__ void igrf_core(const FieldConst &f, const float (&xg)
   // The points of one stencil lie within 1e-6 of each other: they share the truncation degree unless r + 2 crosses an
   // integer between them.  Then ONE predicate per lane and trip covers all NP chains (the per-point form below costs
   // an exec-mask save/restore per point and trip).
-  bool samek = true;
+  // A point on the polar axis (sin(colatitude) < 1e-5: `pole`) sums the phi component with dP in place of P; a wave that
+  // holds such a point takes the per-point form too (practically never: the paired form then carries no select for it).
+  bool samek = !pole[0];
 #pragma unroll
-  for (int i = 1; i < NP; ++i) samek = samek && k[i] == k[0];
+  for (int i = 1; i < NP; ++i) samek = samek && k[i] == k[0] && !pole[i];
   bool paired = false;
   if constexpr (NP > 2) if (__all(samek)) {
     paired = true;
@@ -149,7 +151,6 @@ __device__ __forceinline__ void igrf_core(const FieldConst &f, const float (&xg)
     constexpr int NQ = (NP + 1) / 2;
     const int kl = k[0];
     f2_t C[NQ], S[NQ], CF[NQ], SF[NQ], PP[NQ], P[NQ], D[NQ], BR[NQ], BT[NQ], BF[NQ], X[NQ], Y[NQ], AM[NQ];
-    bool pa[NQ], pb[NQ], polar = false;
 #pragma unroll
     for (int j = 0; j < NQ; ++j) {
       const int a = 2 * j, b = 2 * j + 1 < NP ? 2 * j + 1 : NP - 1;
@@ -158,16 +159,12 @@ __device__ __forceinline__ void igrf_core(const FieldConst &f, const float (&xg)
       CF[j] = f2_t{cf[a], cf[b]};
       SF[j] = f2_t{sf[a], sf[b]};
       PP[j] = f2_t{pp[a], pp[b]};
-      pa[j] = pole[a];
-      pb[j] = pole[b];
-      polar = polar || pa[j] || pb[j];
       P[j] = Y[j] = f2_t{1.f, 1.f};
       D[j] = BR[j] = BT[j] = BF[j] = X[j] = f2_t{0.f, 0.f};
       AM[j] = PP[j] * PP[j];
     }
-    const bool anypole = __any(polar); // wave-uniform
     for (int m = 1; m <= kmax; ++m) {
-      f2_t Q[NQ], Z[NQ], BI[NQ], BIZ[NQ], P2[NQ], D2[NQ], AN[NQ];
+      f2_t Q[NQ], Z[NQ], BI[NQ], P2[NQ], D2[NQ], AN[NQ];
       const bool mlive = m <= kl;
 #pragma unroll
       for (int j = 0; j < NQ; ++j) {
@@ -178,7 +175,7 @@ __device__ __forceinline__ void igrf_core(const FieldConst &f, const float (&xg)
         }
         Q[j] = P[j];
         Z[j] = D[j];
-        BI[j] = BIZ[j] = P2[j] = D2[j] = f2_t{0.f, 0.f};
+        BI[j] = P2[j] = D2[j] = f2_t{0.f, 0.f};
         AN[j] = AM[j];
       }
       const int base = igrf_off(m) - m;
@@ -211,17 +208,13 @@ __device__ __forceinline__ void igrf_core(const FieldConst &f, const float (&xg)
           IGRF_ROW_(u, AN[j] * w[j]);
           IGRF_ROW_(u, u[j] * z[j]);
           IGRF_ROW_(BT, BT[j] - u[j]);
-          if (m != 1) {
+          if (m != 1) { // (a compile-time flag for it -- two copies of the loop -- measured: no faster)
             IGRF_ROW_(t1, e * X[j]);
             IGRF_ROW_(t2, hh * Y[j]);
             IGRF_ROW_(w, t1[j] - t2[j]);
             IGRF_ROW_(w, AN[j] * w[j]);
             IGRF_ROW_(u, w[j] * q[j]);
             IGRF_ROW_(BI, BI[j] + u[j]);
-            if (anypole) { // (a lane on the polar axis sums with z in place of q: the sum it will pick at the end of this m)
-              IGRF_ROW_(u, w[j] * z[j]);
-              IGRF_ROW_(BIZ, BIZ[j] + u[j]);
-            }
           }
           IGRF_ROW_(t1, C[j] * z[j]);
           IGRF_ROW_(t2, S[j] * q[j]);
@@ -244,7 +237,7 @@ __device__ __forceinline__ void igrf_core(const FieldConst &f, const float (&xg)
         for (int j = 0; j < NQ; ++j) {
           D[j] = S[j] * D[j] + C[j] * P[j];
           P[j] = S[j] * P[j];
-          if (m != 1) BF[j] = BF[j] + f2_t{pa[j] ? BIZ[j].x : BI[j].x, pb[j] ? BIZ[j].y : BI[j].y} * (float)(m - 1);
+          if (m != 1) BF[j] = BF[j] + BI[j] * (float)(m - 1);
           AM[j] = AM[j] * PP[j];
         }
       }
