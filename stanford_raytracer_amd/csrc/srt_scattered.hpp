@@ -831,20 +831,56 @@ struct ScatteredModel {
         v8[0] += cw * q7;
         c8[0] += in ? 1 : 0;
       }
+      // the other points' windows, ROW BY ROW over the points with the order pinned (see sf_weights): each point's square
+      // root and series are one dependent chain of ~30 operations; chain j is point j + 1, the free point's only where it
+      // is live and near
+      auto chains = [&](auto nq) {
+        constexpr int NQ = decltype(nq)::value;
+#define SF_ROW(dst, expr)                                                                                              \
+  _Pragma("unroll") for (int j = 0; j < NQ; ++j) dst[j] = expr;                                                        \
+  _Pragma("unroll") for (int j = 0; j < NQ; ++j) asm volatile("" : "+v"(dst[j]))
+        double e0[NQ], e1[NQ], e2[NQ], ss[NQ], y[NQ], g[NQ], h[NQ], r[NQ];
+        SF_ROW(e0, q0 - pg[j + 1][0]);
+        SF_ROW(e1, q1 - pg[j + 1][1]);
+        SF_ROW(e2, q2 - pg[j + 1][2]);
+        SF_ROW(ss, e0[j] * e0[j]);
+        SF_ROW(ss, fma(e1[j], e1[j], ss[j]));
+        SF_ROW(ss, fma(e2[j], e2[j], ss[j]));
+        // fm::sqrt_pos(ss)
+        SF_ROW(y, __builtin_amdgcn_rsq(ss[j]));
+        SF_ROW(g, ss[j] * y[j]);
+        SF_ROW(h, 0.5 * y[j]);
+        SF_ROW(r, fma(-h[j], g[j], 0.5));
+        SF_ROW(g, fma(g[j], r[j], g[j]));
+        SF_ROW(h, fma(h[j], r[j], h[j]));
+        SF_ROW(r, fma(-g[j], g[j], ss[j]));
+        SF_ROW(g, fma(r[j], h[j], g[j]));
+        SF_ROW(r, fma(-g[j], g[j], ss[j]));
+        SF_ROW(g, fma(r[j], h[j], g[j]));
+        SF_ROW(g, ss[j] == 0.0 ? 0.0 : g[j]);
+        SF_ROW(g, g[j] - rc);
+        SF_ROW(g, g[j] * pi_R); // da
+        SF_ROW(y, g[j] * g[j]);
+        SF_ROW(h, fma(y[j], 1.0 / 24.0, -0.5));
+        SF_ROW(r, fma(y[j], 1.0 / 120.0, -1.0 / 6.0));
+        SF_ROW(h, fma(y[j], h[j], 1.0)); // cos da
+        SF_ROW(r, fma(y[j], r[j], 1.0));
+        SF_ROW(r, g[j] * r[j]); // sin da
+        SF_ROW(r, sa * r[j]);
+        SF_ROW(h, fma(ca, h[j], -r[j]));
+        SF_ROW(h, fma(0.5, h[j], 0.5));
+#undef SF_ROW
 #pragma unroll
-      for (int gg = 1; gg < 8; ++gg) {
-        if (gg == 7 && !p7near) continue; // wave-uniform
-        double d0 = q0 - pg[gg][0], d1 = q1 - pg[gg][1], d2 = q2 - pg[gg][2];
-        double ss = d0 * d0 + d1 * d1 + d2 * d2;
-        const bool in = lv8[gg] && ss < r2;
-        double da = (fm::sqrt_pos(ss) - rc) * pi_R, da2 = da * da;
-        double cd = 1.0 + da2 * (-0.5 + da2 * (1.0 / 24.0));
-        double sd = da * (1.0 + da2 * (-1.0 / 6.0 + da2 * (1.0 / 120.0)));
-        const double cw = in ? 0.5 + 0.5 * (ca * cd - sa * sd) : 0.0;
-        s8[gg] += cw;
-        v8[gg] += cw * q7;
-        c8[gg] += in ? 1 : 0;
-      }
+        for (int j = 0; j < NQ; ++j) {
+          const bool in = lv8[j + 1] && ss[j] < r2;
+          const double cw = in ? h[j] : 0.0;
+          s8[j + 1] += cw;
+          v8[j + 1] += cw * q7;
+          c8[j + 1] += in ? 1 : 0;
+        }
+      };
+      if (p7near && lv8[7]) chains(std::integral_constant<int, 7>{}); // (wave-uniform)
+      else chains(std::integral_constant<int, 6>{});
       if (npts > 7 && !p7near) { // a far free point: its own cosine
         double d0 = q0 - pg[7][0], d1 = q1 - pg[7][1], d2 = q2 - pg[7][2];
         double ss = d0 * d0 + d1 * d1 + d2 * d2;
@@ -945,36 +981,72 @@ struct ScatteredModel {
       const bool dir6 = !(base_ok && tb6 <= 1.0e-3 && u * 1.2 * tb6 <= 1.0e-3);
       const bool dir7 = dir6 || !(p7near && tb7 <= 1.0e-3 && u * 1.2 * tb7 <= 1.0e-3);
       double w8[8];
-#pragma unroll
-      for (int gg = 0; gg < 8; ++gg) {
+      w8[0] = fit8[0] && ssc < r2 ? E * (0.5 + 0.5 * ca) : 0.0; // strictly inside (kdtree_mod.f95:171)
+      w8[7] = 0.0;
+      // The series of the other points, written ROW BY ROW over the points with the order pinned (an empty volatile asm per
+      // result, as in igrf_core, srt_device.hpp): each point's ~40 operations are one dependent chain (three Horner forms in
+      // a row), an instruction issued right behind its producer waits ~5 ns instead of 2, and left to itself the scheduler
+      // emits the chains one after the other.  Chain j is point j + 1; the free point's chain only where it has a fit.
+      auto chains = [&](auto nq) {
+        constexpr int NQ = decltype(nq)::value;
+#define SF_ROW(dst, expr)                                                                                              \
+  _Pragma("unroll") for (int j = 0; j < NQ; ++j) dst[j] = expr;                                                        \
+  _Pragma("unroll") for (int j = 0; j < NQ; ++j) asm volatile("" : "+v"(dst[j]))
         // t = r_g^2 - r_c^2 from the offset itself
-        double t;
-        if (gg == 0) t = 0.0;
-        else if (gg == 7) t = o7sq - 2.0 * (o7[0] * dc[0] + o7[1] * dc[1] + o7[2] * dc[2]);
-        else {
-          const int ax = (gg - 1) >> 1;
-          const double dl = (gg & 1) ? da3[ax] : mda3[ax];
-          t = dl * (dl - 2.0 * dc[ax]);
+        double t[NQ], tin[NQ], pl[NQ], dr[NQ], au[NQ], X[NQ], cd[NQ], sd[NQ];
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+          if (j < 6) {
+            const double dl = (j & 1) ? mda3[j >> 1] : da3[j >> 1];
+            const double x = fma(-2.0, dc[j >> 1], dl);
+            t[j] = dl * x;
+            tin[j] = fma(dl, x, ssc);
+          } else {
+            t[j] = o7sq - 2.0 * (o7[0] * dc[0] + o7[1] * dc[1] + o7[2] * dc[2]);
+            tin[j] = ssc + t[j];
+          }
         }
-        const bool in = fit8[gg] && ssc + t < r2; // strictly inside (kdtree_mod.f95:171)
-        double e;
-        if (gg == 0) {
-          e = E * (0.5 + 0.5 * ca);
-        } else {
-          const double eps = t * inv2;
-          const double dr = (0.5 * t * inv) * (1.0 + eps * (-0.25 + eps * (0.125 + eps * (-0.078125 + eps * 0.0546875))));
-          const double tau = (dr * inv) * (1.0 + eta8[gg]) + eta8[gg];
-          const double sp = tau * (1.1 + tau * (0.055 + tau * (-0.0165 + tau * (0.0078375 + tau * -0.00454575))));
-          const double du = u * sp;
-          const double X = 1.0 + du * (-1.0 + du * (0.5 + du * (-1.0 / 6.0 + du * (1.0 / 24.0 + du * (-1.0 / 120.0 + du * (1.0 / 720.0))))));
-          const double dan = dr * pi_R, da2 = dan * dan;
-          const double cd = 1.0 + da2 * (-0.5 + da2 * (1.0 / 24.0));
-          const double sd = dan * (1.0 + da2 * (-1.0 / 6.0 + da2 * (1.0 / 120.0)));
-          e = E * X * (0.5 + 0.5 * (ca * cd - sa * sd));
-        }
-        w8[gg] = in ? e : 0.0;
-      }
-      if (dir7) { // rare, per lane: etainv() itself at the points that cannot take the series
+        SF_ROW(au, t[j] * inv2); // eps
+        SF_ROW(pl, fma(au[j], 0.0546875, -0.078125));
+        SF_ROW(pl, fma(au[j], pl[j], 0.125));
+        SF_ROW(pl, fma(au[j], pl[j], -0.25));
+        SF_ROW(pl, fma(au[j], pl[j], 1.0));
+        SF_ROW(dr, 0.5 * t[j]);
+        SF_ROW(dr, dr[j] * inv);
+        SF_ROW(dr, dr[j] * pl[j]);
+        SF_ROW(au, dr[j] * inv); // tau
+        SF_ROW(au, fma(au[j], 1.0 + eta8[j + 1], eta8[j + 1]));
+        SF_ROW(pl, fma(au[j], -0.00454575, 0.0078375));
+        SF_ROW(pl, fma(au[j], pl[j], -0.0165));
+        SF_ROW(pl, fma(au[j], pl[j], 0.055));
+        SF_ROW(pl, fma(au[j], pl[j], 1.1));
+        SF_ROW(au, au[j] * pl[j]); // (1 + tau)**1.1 - 1
+        SF_ROW(au, u * au[j]);     // du
+        SF_ROW(pl, fma(au[j], 1.0 / 720.0, -1.0 / 120.0));
+        SF_ROW(pl, fma(au[j], pl[j], 1.0 / 24.0));
+        SF_ROW(pl, fma(au[j], pl[j], -1.0 / 6.0));
+        SF_ROW(pl, fma(au[j], pl[j], 0.5));
+        SF_ROW(pl, fma(au[j], pl[j], -1.0));
+        SF_ROW(X, fma(au[j], pl[j], 1.0)); // exp(-du)
+        SF_ROW(dr, dr[j] * pi_R);          // da
+        SF_ROW(au, dr[j] * dr[j]);
+        SF_ROW(cd, fma(au[j], 1.0 / 24.0, -0.5));
+        SF_ROW(sd, fma(au[j], 1.0 / 120.0, -1.0 / 6.0));
+        SF_ROW(cd, fma(au[j], cd[j], 1.0));
+        SF_ROW(sd, fma(au[j], sd[j], 1.0));
+        SF_ROW(sd, dr[j] * sd[j]);
+        SF_ROW(sd, sa * sd[j]);
+        SF_ROW(X, E * X[j]);
+        SF_ROW(cd, fma(ca, cd[j], -sd[j]));
+        SF_ROW(cd, fma(cd[j], 0.5, 0.5));
+        SF_ROW(X, X[j] * cd[j]);
+#undef SF_ROW
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) w8[j + 1] = (fit8[j + 1] && tin[j] < r2) ? X[j] : 0.0;
+      };
+      if (fit8[7]) chains(std::integral_constant<int, 7>{}); // (wave-uniform)
+      else chains(std::integral_constant<int, 6>{});
+      if (dir6 || (dir7 && fit8[7])) { // rare, per lane: etainv() itself at the points that cannot take the series
 #pragma unroll 1
         for (int gg = 0; gg < 8; ++gg) {
           if (gg < 7 && !dir6) continue;
