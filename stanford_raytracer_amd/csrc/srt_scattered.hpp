@@ -564,6 +564,37 @@ struct ScatteredModel {
     v += dpp_move<0x141>(v); // row_half_mirror
     return v;
   }
+  // two sums over the 8 lanes of a group at once: the total of `a` lands in the group's lanes 0..3, that of `b` in lanes 4..7
+  // (the halves swap what they do not keep through row_half_mirror -- lane i takes lane 7 - i's -- then xor 1, xor 2 within
+  // the quad)
+  __device__ __forceinline__ static double group_sum2(double a, double b) {
+    const bool low = (threadIdx.x & 4) == 0;
+    const double keep = low ? a : b, send = low ? b : a;
+    double v = keep + dpp_move<0x141>(send);
+    v += dpp_move<0xB1>(v);
+    v += dpp_move<0x4E>(v);
+    return v;
+  }
+  // Eight sums over the 8 lanes of a group at once, transposed: lane `sub` of the group ends with the group's total of
+  // x[rev3(sub)] (rev3: the three bits of sub reversed).  Three halving levels -- the halves / quad halves / neighbours swap what
+  // they do not keep (row_half_mirror, quad_perm [2,3,0,1], quad_perm [1,0,3,2]) -- 4 + 2 + 1 exchanges of 7 operations.
+  __device__ __forceinline__ static double group_transpose_sum(const double (&x)[8]) {
+    const int sub = threadIdx.x & 7;
+    const bool b2 = (sub & 4) != 0, b1 = (sub & 2) != 0, b0 = (sub & 1) != 0;
+    double y[4], z[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) y[i] = (b2 ? x[2 * i + 1] : x[2 * i]) + dpp_move<0x141>(b2 ? x[2 * i] : x[2 * i + 1]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) z[i] = (b1 ? y[2 * i + 1] : y[2 * i]) + dpp_move<0x4E>(b1 ? y[2 * i] : y[2 * i + 1]);
+    return (b0 ? z[1] : z[0]) + dpp_move<0xB1>(b0 ? z[0] : z[1]);
+  }
+  // sum over the 8 groups of what each lane holds (lanes with the same `sub`), every lane gets its total
+  __device__ __forceinline__ static double across_groups(double v) {
+    v += dpp_move<0x128>(v); // row_ror:8 -- the other group of the row
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+  }
   __device__ __forceinline__ static int group_sum(int v) {
     v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);
     v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);
@@ -699,13 +730,31 @@ struct ScatteredModel {
     return 0;
   }
 
-  // sum over all 64 lanes (every lane gets the total)
-  __device__ __forceinline__ static double wave_sum(double v) {
+  // Wave-wide reductions in registers, returned wave-uniform (DPP: within the group of 8, row_mirror for the row of 16,
+  // row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3 -- lane 63 then holds the result).
+  template <int CTRL, int ROWS>
+  __device__ __forceinline__ static double dpp_move_rows(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROWS, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROWS, 0xF, false);
+    return __hiloint2double(hi, lo);
+  }
+  // largest of 64 non-negative numbers (the rows a masked step leaves out see 0), wave-uniform
+  __device__ __forceinline__ static double wave_max_nonneg(double v) {
+    v = fmax(v, dpp_move<0xB1>(v));
+    v = fmax(v, dpp_move<0x4E>(v));
+    v = fmax(v, dpp_move<0x141>(v));
+    v = fmax(v, dpp_move<0x140>(v));
+    v = fmax(v, dpp_move_rows<0x142, 0xA>(v));
+    v = fmax(v, dpp_move_rows<0x143, 0xC>(v));
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+  }
+  __device__ __forceinline__ static int wave_total(int v) {
     v = group_sum(v);
-    v += __shfl_xor(v, 8);
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
-    return v;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);
+    return __builtin_amdgcn_readlane(v, 63);
   }
 
   // the LDS list area: 8 own lists of LIST_CAP entries, or one shared list
@@ -728,8 +777,8 @@ struct ScatteredModel {
   //              with t_g = r_g^2 - r_c^2 = delta (delta -+ 2 d_a) taken from the offsets directly (no cancellation, no
   //              square root), eps = t_g / r_c^2, dr = (t_g / 2 r_c)(1 - eps/4 + eps^2/8 - 5 eps^3/64 + 7 eps^4/128)
   //              (|eps| <= 2e-3: remainder 1e-15 dr), tau = (1 + dr/(r_c + R eps0)) (h_c/h_g) - 1:
-  //                  x_g**1.1 = u_c (1 + tau)**1.1            binomial series to tau^5     (|tau| <= 1e-3: remainder 3e-21)
-  //                  exp(-u_g) = E_c exp(-du), du = u_g - u_c  exponential series to du^6   (|du| <= 1.2e-3: remainder 7e-25)
+  //                  x_g**1.1 = u_c (1 + tau)**1.1            binomial series to tau^4     (|tau| <= 1e-3: remainder 5e-18)
+  //                  exp(-u_g) = E_c exp(-du), du = u_g - u_c  exponential series to du^5   (|du| <= 1.2e-3: remainder 4e-21)
   //                  cos(a_c + da) = ca cos da - sa sin da
   //              i.e. the same numbers as etainv() to within its own rounding (both carry ~u_c * 2^-53 from the rounding
   //              of r).  u_c = a sh with a = (r_c + R eps0)**1.1 and sh = (h_c / 4)**-1.1.  Samples for which the bounds
@@ -780,7 +829,7 @@ struct ScatteredModel {
   // p7near: the free point 7 lies as close to the centre as the six offset points may (<= 1e-3 radius) and takes the
   // addition theorem / the series like them; else its window is evaluated by cos() and its weight by etainv().
   __device__ __forceinline__ void sf_pass1(const double (&p_in)[3], unsigned long long livemask, int npts, int n_list,
-                                        SRT_LDS const int *list, double *rec_flat, bool p7near) const {
+                                        SRT_LDS const int *list, double *rec_flat, double dmax6, double d7, bool p7near) const {
     const ScatteredModel M = uniform_copy();
     const double p[3] = {p_in[0], p_in[1], p_in[2]};
     const double radius = M.radius, lws = M.lws;
@@ -805,6 +854,12 @@ struct ScatteredModel {
 #pragma unroll
     for (int gg = 0; gg < 8; ++gg) lv8[gg] = (livemask >> (8 * gg)) & 1ull; // wave-uniform
     const Side side = side_of(list, n_list);
+    // the points' offsets from the centre (as in sf_weights)
+    const double reps = radius * 5.0e-16;
+    const double da3[3] = {pg[1][0] - pg[0][0], pg[3][1] - pg[0][1], pg[5][2] - pg[0][2]};
+    const double mda3[3] = {pg[2][0] - pg[0][0], pg[4][1] - pg[0][1], pg[6][2] - pg[0][2]};
+    const double o7[3] = {pg[7][0] - pg[0][0], pg[7][1] - pg[0][1], pg[7][2] - pg[0][2]};
+    const double o7sq = o7[0] * o7[0] + o7[1] * o7[1] + o7[2] * o7[2];
     // (one sample ahead: the next gather is in flight while this sample is worked on)
     d2_t na = {0.0, 0.0}, nb = na, nc = na, nd = na;
     if (lane < n_list) {
@@ -820,9 +875,10 @@ struct ScatteredModel {
       }
       const double q0 = qa.x, q1 = qa.y, q2 = qb.x, q7 = qd.y;
       double rc, ca, sa;
+      const double dc[3] = {q0 - pg[0][0], q1 - pg[0][1], q2 - pg[0][2]};
+      const double ssc = dc[0] * dc[0] + dc[1] * dc[1] + dc[2] * dc[2];
       {
-        double d0 = q0 - pg[0][0], d1 = q1 - pg[0][1], d2 = q2 - pg[0][2];
-        double ss = d0 * d0 + d1 * d1 + d2 * d2;
+        const double ss = ssc;
         rc = fm::sqrt_pos(ss);
         fm::sincos_0pi(rc * pi_R, sa, ca);
         const bool in = lv8[0] && ss < r2;
@@ -831,48 +887,59 @@ struct ScatteredModel {
         v8[0] += cw * q7;
         c8[0] += in ? 1 : 0;
       }
-      // the other points' windows, ROW BY ROW over the points with the order pinned (see sf_weights): each point's square
-      // root and series are one dependent chain of ~30 operations; chain j is point j + 1, the free point's only where it
-      // is live and near
+      // The other points' windows.  da_g = (r_g - r_c) pi / R from t_g = r_g^2 - r_c^2 = delta (delta -+ 2 d_a), taken from the
+      // offsets directly, by the series sf_weights uses (same dr_g there: the windows and the weights of a sample see the same
+      // number) -- no square root per point; ROW BY ROW over the points with the order pinned (see sf_weights); chain j is
+      // point j + 1, the free point's only where it is live and near.  A sample too close to the centre for the series
+      // (|eps| <= 2e-3 needs the offsets within 1e-3 r_c) takes the square roots (per lane; rare).
+      const double inv = fdiv(1.0, rc + reps), inv2 = inv * inv, hinv = 0.5 * inv;
       auto chains = [&](auto nq) {
         constexpr int NQ = decltype(nq)::value;
 #define SF_ROW(dst, expr)                                                                                              \
   _Pragma("unroll") for (int j = 0; j < NQ; ++j) dst[j] = expr;                                                        \
   _Pragma("unroll") for (int j = 0; j < NQ; ++j) asm volatile("" : "+v"(dst[j]))
-        double e0[NQ], e1[NQ], e2[NQ], ss[NQ], y[NQ], g[NQ], h[NQ], r[NQ];
-        SF_ROW(e0, q0 - pg[j + 1][0]);
-        SF_ROW(e1, q1 - pg[j + 1][1]);
-        SF_ROW(e2, q2 - pg[j + 1][2]);
-        SF_ROW(ss, e0[j] * e0[j]);
-        SF_ROW(ss, fma(e1[j], e1[j], ss[j]));
-        SF_ROW(ss, fma(e2[j], e2[j], ss[j]));
-        // fm::sqrt_pos(ss)
-        SF_ROW(y, __builtin_amdgcn_rsq(ss[j]));
-        SF_ROW(g, ss[j] * y[j]);
-        SF_ROW(h, 0.5 * y[j]);
-        SF_ROW(r, fma(-h[j], g[j], 0.5));
-        SF_ROW(g, fma(g[j], r[j], g[j]));
-        SF_ROW(h, fma(h[j], r[j], h[j]));
-        SF_ROW(r, fma(-g[j], g[j], ss[j]));
-        SF_ROW(g, fma(r[j], h[j], g[j]));
-        SF_ROW(r, fma(-g[j], g[j], ss[j]));
-        SF_ROW(g, fma(r[j], h[j], g[j]));
-        SF_ROW(g, ss[j] == 0.0 ? 0.0 : g[j]);
-        SF_ROW(g, g[j] - rc);
-        SF_ROW(g, g[j] * pi_R); // da
-        SF_ROW(y, g[j] * g[j]);
+        double t[NQ], tin[NQ], eps[NQ], pl[NQ], da[NQ], y[NQ], h[NQ], r[NQ];
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+          if (j < 6) {
+            const double dl = (j & 1) ? mda3[j >> 1] : da3[j >> 1];
+            const double x = fma(-2.0, dc[j >> 1], dl);
+            t[j] = dl * x;
+            tin[j] = fma(dl, x, ssc);
+          } else {
+            t[j] = o7sq - 2.0 * (o7[0] * dc[0] + o7[1] * dc[1] + o7[2] * dc[2]);
+            tin[j] = ssc + t[j];
+          }
+        }
+        SF_ROW(eps, t[j] * inv2);
+        SF_ROW(pl, fma(eps[j], 0.0546875, -0.078125));
+        SF_ROW(pl, fma(eps[j], pl[j], 0.125));
+        SF_ROW(pl, fma(eps[j], pl[j], -0.25));
+        SF_ROW(pl, fma(eps[j], pl[j], 1.0));
+        SF_ROW(da, t[j] * hinv);
+        SF_ROW(da, da[j] * pl[j]);
+        SF_ROW(da, da[j] * pi_R);
+        if (!(dmax6 * inv <= 1.0e-3) || (NQ == 7 && !(d7 * inv <= 1.0e-3))) { // per lane, rare
+#pragma unroll
+          for (int j = 0; j < NQ; ++j) {
+            const double e0 = q0 - pg[j + 1][0], e1 = q1 - pg[j + 1][1], e2 = q2 - pg[j + 1][2];
+            tin[j] = e0 * e0 + e1 * e1 + e2 * e2;
+            da[j] = (fm::sqrt_pos(tin[j]) - rc) * pi_R;
+          }
+        }
+        SF_ROW(y, da[j] * da[j]);
         SF_ROW(h, fma(y[j], 1.0 / 24.0, -0.5));
         SF_ROW(r, fma(y[j], 1.0 / 120.0, -1.0 / 6.0));
         SF_ROW(h, fma(y[j], h[j], 1.0)); // cos da
         SF_ROW(r, fma(y[j], r[j], 1.0));
-        SF_ROW(r, g[j] * r[j]); // sin da
+        SF_ROW(r, da[j] * r[j]); // sin da
         SF_ROW(r, sa * r[j]);
         SF_ROW(h, fma(ca, h[j], -r[j]));
         SF_ROW(h, fma(0.5, h[j], 0.5));
 #undef SF_ROW
 #pragma unroll
         for (int j = 0; j < NQ; ++j) {
-          const bool in = lv8[j + 1] && ss[j] < r2;
+          const bool in = lv8[j + 1] && tin[j] < r2; // strictly inside (kdtree_mod.f95:171)
           const double cw = in ? h[j] : 0.0;
           s8[j + 1] += cw;
           v8[j + 1] += cw * q7;
@@ -914,14 +981,23 @@ struct ScatteredModel {
     }
     SRT_PHASE(1);
     SRT_LDS Pass1Out *o = pass1_out(list);
+    // The kernel is bound by the vector-instruction issue rate, so the 16 sums are reduced TRANSPOSED (group_transpose_sum:
+    // 8 sums -> one register, lane `sub` of every group holding the group's total of sum rev3(sub): 49 operations for 8 sums),
+    // then over the 8 groups (row_ror:8 in registers, xor 16 and xor 32 through ds_bpermute, which does not take a vector
+    // issue slot): every lane ends with the wave totals of ITS sum, and one division per lane replaces eight.
+    int n8[8];
+    const double ts = across_groups(group_transpose_sum(s8)), tv = across_groups(group_transpose_sum(v8));
+    const double hmine = lws * (tv / ts);
+    const int rev3 = ((lane & 1) << 2) | (lane & 2) | ((lane >> 2) & 1);
 #pragma unroll
-    for (int gg = 0; gg < 8; ++gg) {
-      const double ts = wave_sum(s8[gg]), tv = wave_sum(v8[gg]);
-      const int cn = (int)wave_sum((double)c8[gg]);
-      if (lane == 0) {
-        o->hin8[gg] = lws * (tv / ts);
-        o->cnt8[gg] = cn;
-      }
+    for (int gg = 0; gg < 8; gg += 2) { // (a lane counts at most REC_CAP / 64 samples, the wave REC_CAP: 16 bits each)
+      const int two = wave_total(c8[gg] | (c8[gg + 1] << 16));
+      n8[gg] = two & 0xFFFF, n8[gg + 1] = (int)((unsigned)two >> 16);
+    }
+    if (lane < 8) o->hin8[rev3] = hmine;
+    if (lane == 0) {
+#pragma unroll
+      for (int gg = 0; gg < 8; ++gg) o->cnt8[gg] = n8[gg];
     }
     __syncthreads(); // block == one wave: the records and the sums written above are read by other lanes next
     SRT_PHASE(2);
@@ -972,7 +1048,7 @@ struct ScatteredModel {
       const double ssc = dc[0] * dc[0] + dc[1] * dc[1] + dc[2] * dc[2];
       const double xr = rc + reps;
       const double a11 = xr * fm::exp_any(0.1 * fm::log_pos(xr));
-      const double inv = fdiv(1.0, xr), inv2 = inv * inv;
+      const double inv = fdiv(1.0, xr), inv2 = inv * inv, hinv = 0.5 * inv;
       const double u = a11 * sh;
       const double E = fm::exp_any(-u);
       double tb6 = dmax6 * inv, tb7 = d7 * inv;
@@ -981,7 +1057,11 @@ struct ScatteredModel {
       const bool dir6 = !(base_ok && tb6 <= 1.0e-3 && u * 1.2 * tb6 <= 1.0e-3);
       const bool dir7 = dir6 || !(p7near && tb7 <= 1.0e-3 && u * 1.2 * tb7 <= 1.0e-3);
       double w8[8];
-      w8[0] = fit8[0] && ssc < r2 ? E * (0.5 + 0.5 * ca) : 0.0; // strictly inside (kdtree_mod.f95:171)
+      // (HALF-weights from here on: 0.5 E is exact, so 0.5 E X W are the bits of 0.5 (E X W); the reference's mask
+      // weight > 1e-16 (:316-317) is the same test on the halves)
+      const double Eh = 0.5 * E, thr = 0.5 * 1.0e-16;
+      const double w0 = Eh * (0.5 + 0.5 * ca);
+      w8[0] = (fit8[0] && ssc < r2 && (w0 > thr || !usemask)) ? w0 : 0.0; // strictly inside (kdtree_mod.f95:171)
       w8[7] = 0.0;
       // The series of the other points, written ROW BY ROW over the points with the order pinned (an empty volatile asm per
       // result, as in igrf_core, srt_device.hpp): each point's ~40 operations are one dependent chain (three Horner forms in
@@ -1011,19 +1091,16 @@ struct ScatteredModel {
         SF_ROW(pl, fma(au[j], pl[j], 0.125));
         SF_ROW(pl, fma(au[j], pl[j], -0.25));
         SF_ROW(pl, fma(au[j], pl[j], 1.0));
-        SF_ROW(dr, 0.5 * t[j]);
-        SF_ROW(dr, dr[j] * inv);
+        SF_ROW(dr, t[j] * hinv); // (= (0.5 t) inv to the bit)
         SF_ROW(dr, dr[j] * pl[j]);
         SF_ROW(au, dr[j] * inv); // tau
         SF_ROW(au, fma(au[j], 1.0 + eta8[j + 1], eta8[j + 1]));
-        SF_ROW(pl, fma(au[j], -0.00454575, 0.0078375));
-        SF_ROW(pl, fma(au[j], pl[j], -0.0165));
+        SF_ROW(pl, fma(au[j], 0.0078375, -0.0165));
         SF_ROW(pl, fma(au[j], pl[j], 0.055));
         SF_ROW(pl, fma(au[j], pl[j], 1.1));
         SF_ROW(au, au[j] * pl[j]); // (1 + tau)**1.1 - 1
         SF_ROW(au, u * au[j]);     // du
-        SF_ROW(pl, fma(au[j], 1.0 / 720.0, -1.0 / 120.0));
-        SF_ROW(pl, fma(au[j], pl[j], 1.0 / 24.0));
+        SF_ROW(pl, fma(au[j], -1.0 / 120.0, 1.0 / 24.0));
         SF_ROW(pl, fma(au[j], pl[j], -1.0 / 6.0));
         SF_ROW(pl, fma(au[j], pl[j], 0.5));
         SF_ROW(pl, fma(au[j], pl[j], -1.0));
@@ -1036,13 +1113,13 @@ struct ScatteredModel {
         SF_ROW(sd, fma(au[j], sd[j], 1.0));
         SF_ROW(sd, dr[j] * sd[j]);
         SF_ROW(sd, sa * sd[j]);
-        SF_ROW(X, E * X[j]);
+        SF_ROW(X, Eh * X[j]);
         SF_ROW(cd, fma(ca, cd[j], -sd[j]));
         SF_ROW(cd, fma(cd[j], 0.5, 0.5));
         SF_ROW(X, X[j] * cd[j]);
 #undef SF_ROW
 #pragma unroll
-        for (int j = 0; j < NQ; ++j) w8[j + 1] = (fit8[j + 1] && tin[j] < r2) ? X[j] : 0.0;
+        for (int j = 0; j < NQ; ++j) w8[j + 1] = (fit8[j + 1] && tin[j] < r2 && (X[j] > thr || !usemask)) ? X[j] : 0.0;
       };
       if (fit8[7]) chains(std::integral_constant<int, 7>{}); // (wave-uniform)
       else chains(std::integral_constant<int, 6>{});
@@ -1060,13 +1137,12 @@ struct ScatteredModel {
           }
           const double e0 = q0 - px, e1 = q1 - py, e2 = q2 - pz;
           const double ss = e0 * e0 + e1 * e1 + e2 * e2;
-          const double e = (fg && ss < r2) ? M.etainv_at(ss, hg) : 0.0;
+          double e = (fg && ss < r2) ? 0.5 * M.etainv_at(ss, hg) : 0.0;
+          e = (usemask && !(e > thr)) ? 0.0 : e; // :316-317
 #pragma unroll
           for (int t = 0; t < 8; ++t) w8[t] = gg == t ? e : w8[t];
         }
       }
-#pragma unroll
-      for (int gg = 0; gg < 8; ++gg) w8[gg] = (usemask && !(w8[gg] > 1.0e-16)) ? 0.0 : 0.5 * w8[gg]; // :316-317
       *chunk(rec, 4, k) = d2_t{w8[0], w8[1]};
       *chunk(rec, 5, k) = d2_t{w8[2], w8[3]};
       *chunk(rec, 6, k) = d2_t{w8[4], w8[5]};
@@ -1234,18 +1310,24 @@ struct ScatteredModel {
         }
       } else if constexpr (J == 10) {
         SRT_LDS double *area = (SRT_LDS double *)const_cast<SRT_LDS int *>(list) + 80 * g; // (the ring is dead by now)
-#pragma unroll
-        for (int t = 0; t < Moments::N; ++t) {
-          const double v = group_sum(Mm[t]);
-          if (sub == (t & 7)) area[t] = v;
-        }
-#pragma unroll
-        for (int a = 0; a < 10; ++a)
-#pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            const double v = group_sum(b[a][s]);
-            if (sub == ((4 * a + s) & 7)) area[35 + 4 * a + s] = v;
+        // the 75 sums two at a time (group_sum2: 13 instead of 18 operations per two sums); sum t's total lands in
+        // sub-lanes 0..3, sum t + 1's in 4..7, and one lane of each half parks it
+        static_assert(Moments::N == 35, "area layout: 35 moments, then 10 x 4 right-hand sums");
+        auto sumof = [&](auto ic) -> double {
+          constexpr int t = decltype(ic)::value;
+          if constexpr (t < 35) return Mm[t];
+          else if constexpr (t < 75) return b[(t - 35) >> 2][(t - 35) & 3];
+          else return 0.0;
+        };
+        auto pairs = [&](auto self, auto ic) -> void {
+          constexpr int t = decltype(ic)::value;
+          if constexpr (t < 75) {
+            const double v = group_sum2(sumof(std::integral_constant<int, t>{}), sumof(std::integral_constant<int, t + 1>{}));
+            if ((sub & 3) == ((t >> 1) & 3) && t + (sub >> 2) < 75) area[t + (sub >> 2)] = v;
+            self(self, std::integral_constant<int, t + 2>{});
           }
+        };
+        pairs(pairs, std::integral_constant<int, 0>{});
         __syncthreads(); // block == one wave: the totals written above are read by the group's other lanes below
         if (fit) {
           double f4[4];
@@ -1280,7 +1362,7 @@ struct ScatteredModel {
   template <int J>
   __device__ __noinline__ bool sf_prepare(const double (&p)[3], bool live, unsigned long long livemask, int npts, int n_list,
                                           SRT_LDS const int *list, double *rec, double dmax6, double d7, bool p7near) const {
-    sf_pass1(p, livemask, npts, n_list, list, rec, p7near);
+    sf_pass1(p, livemask, npts, n_list, list, rec, dmax6, d7, p7near);
     sf_weights<J>(p, live, livemask, npts, n_list, list, rec, dmax6, d7, p7near, true);
     return live && pass1_out(list)->cnt8[threadIdx.x >> 3] >= J;
   }
@@ -1596,9 +1678,9 @@ struct ScatteredModel {
         double oc[3], od[3], oe[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-          oc[k] = __shfl(c[k], j);
-          od[k] = __shfl(d[k], j);
-          oe[k] = (npts > 7) ? __shfl(extra[k], j) : 0.0;
+          oc[k] = from_lane(c[k], j); // (j is wave-uniform: v_readlane, no LDS round trip)
+          od[k] = from_lane(d[k], j);
+          oe[k] = (npts > 7) ? from_lane(extra[k], j) : 0.0;
         }
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -1638,14 +1720,12 @@ struct ScatteredModel {
       // ---- candidates of the shared path
       double pc[3];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) pc[k] = __shfl(p[k], 0);
+      for (int k = 0; k < 3; ++k) pc[k] = from_lane(p[k], 0);
       // distance of this group's point from the centre; dmax: of the six offset points, d7: of the free point
       const double e2own = (g < npts) ? (p[0] - pc[0]) * (p[0] - pc[0]) + (p[1] - pc[1]) * (p[1] - pc[1]) + (p[2] - pc[2]) * (p[2] - pc[2]) : 0.0;
       double e2s = (g < 7) ? e2own : 0.0;
-      e2s = fmax(e2s, __shfl_xor(e2s, 8));
-      e2s = fmax(e2s, __shfl_xor(e2s, 16));
-      e2s = fmax(e2s, __shfl_xor(e2s, 32));
-      const double e27 = __shfl(e2own, 56); // 0 when there is no free point
+      e2s = wave_max_nonneg(e2s);
+      const double e27 = from_lane(e2own, 56); // 0 when there is no free point
       const double dmax = sqrt(e2s), d7 = sqrt(e27), ext = fmax(dmax, d7);
       const bool p7near = npts > 7 && d7 <= 1.0e-3 * radius;
       const bool geom = rec != nullptr && dmax <= 1.0e-3 * radius;
@@ -1685,7 +1765,8 @@ struct ScatteredModel {
         }
       }
       if (!shared && geom &&
-          !__any(g < npts && (cx != __shfl(cx, 0) || R.cy != __shfl(R.cy, 0) || R.cz != __shfl(R.cz, 0)))) {
+          !__any(g < npts && (cx != __builtin_amdgcn_readlane(cx, 0) || R.cy != __builtin_amdgcn_readlane(R.cy, 0) ||
+                              R.cz != __builtin_amdgcn_readlane(R.cz, 0)))) {
         // ---- no block (layered kernels; block overflow): scan the centre's 27 cells
         Rows Rc;
         Rc.cy = __builtin_amdgcn_readlane(R.cy, 0);
