@@ -156,6 +156,13 @@ struct MomentsT {
   __device__ __forceinline__ static void monomials_from(double (&mono)[NM], const double (&d)[3], std::integer_sequence<int, I...>) {
     ((mono[I + 1] = mono[C<I + 1>::par] * d[C<I + 1>::ax]), ...);
   }
+  // the moments of the top degree (indices LOW .. N - 1; their parents have degree 2 ORDER - 1 < LOW): sum += parent * coordinate
+  static constexpr int LOW = mom::count(2 * ORDER - 1);
+  template <int NM, int... I>
+  __device__ __forceinline__ static void fold_leaves(double (&M)[N], const double (&mono)[NM], const double (&d)[3], std::integer_sequence<int, I...>) {
+    static_assert(NM >= LOW, "the products up to degree 2 ORDER - 1");
+    ((M[LOW + I] = fma(mono[C<LOW + I>::par], d[C<LOW + I>::ax], M[LOW + I])), ...);
+  }
   template <int... T>
   __device__ __forceinline__ static void expand(const double (&M)[N], double (&A)[NT], std::integer_sequence<int, T...>) {
     ((A[T] = M[P<T>::mom]), ...);
@@ -166,6 +173,7 @@ struct MomentsT {
   }
 };
 using Moments = MomentsT<2>;
+static_assert(Moments::LOW == 20 && Moments::parent(20) >= 10 && Moments::parent(34) < 20 && Moments::of_m(9) < 10, "degree-4 moments are leaves");
 static_assert(Moments::N == 35 && Moments::J == 10 && MomentsT<3>::N == 84 && MomentsT<3>::J == 20, "moment counts");
 static_assert(Moments::of_m(4) == mom::find(0, 1, 1) && Moments::of_m(9) == mom::find(2, 0, 0) && MomentsT<3>::of_m(19) == mom::find(3, 0, 0) &&
                   MomentsT<3>::of_m(12) == mom::find(1, 0, 2),
@@ -669,7 +677,7 @@ struct ScatteredModel {
 #pragma unroll
       for (int l = 0; l < j; ++l) s -= at(l, j) * at(l, j);
       if (!(s > 0.0)) return 1;
-      const double ujj = sqrt(s), inv = fdiv(1.0, ujj);
+      const double ujj = fm::sqrt_pos(s), inv = fdiv(1.0, ujj); // (a positive pivot of sums of squares of O(1) offsets: normal range)
       at(j, j) = ujj;
       rinv[j] = inv;
 #pragma unroll
@@ -716,17 +724,15 @@ struct ScatteredModel {
   __device__ __forceinline__ static void expand_parked(SRT_LDS const double *area, double (&A)[55], std::integer_sequence<int, T...>) {
     ((A[T] = area[Moments::P<T>::mom]), ...);
   }
-  __device__ __forceinline__ static int solve10_parked(SRT_LDS const double *area, double fi[4]) {
+  // (returns the fit of ONE species, `s`: the hand-off to the owner takes species lane & 3 from each lane)
+  __device__ __forceinline__ static int solve10_parked(SRT_LDS const double *area, int s, double &fi) {
     double A[55], y[10];
     expand_parked(area, A, std::make_integer_sequence<int, 55>{});
     if (chol_y<10>(A, y) != 0) return 1;
+    double acc = 0.0;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      double acc = 0.0;
-#pragma unroll
-      for (int j = 0; j < 10; ++j) acc += y[j] * area[35 + 4 * j + s];
-      fi[s] = acc;
-    }
+    for (int j = 0; j < 10; ++j) acc += y[j] * area[35 + 4 * j + s];
+    fi = acc;
     return 0;
   }
 
@@ -1193,12 +1199,15 @@ struct ScatteredModel {
       } else if constexpr (J == 10) {
         // the weight is folded into the monomials as they are built (w, w x, w x^2 .. : the same 34 products), so the
         // moments take an addition each and the right-hand sums find their w m_a ready made
+        // The 15 moments of degree 4 are leaves of the monomial chain (nothing is built from them, the right-hand sums need
+        // degree <= 2): each is ONE fused multiply-add of its parent's product into its sum instead of a product and an addition.
         const double dd[3] = {d0, d1, d2};
-        double wm[Moments::N], m[10];
+        double wm[Moments::LOW], m[10];
         wm[0] = w2;
-        Moments::monomials_from(wm, dd, std::make_integer_sequence<int, Moments::N - 1>{});
+        Moments::monomials_from(wm, dd, std::make_integer_sequence<int, Moments::LOW - 1>{});
 #pragma unroll
-        for (int i = 0; i < Moments::N; ++i) Mm[i] += wm[i];
+        for (int i = 0; i < Moments::LOW; ++i) Mm[i] += wm[i];
+        Moments::fold_leaves(Mm, wm, dd, std::make_integer_sequence<int, Moments::N - Moments::LOW>{});
         Moments::firsts(wm, m, std::make_integer_sequence<int, 10>{}); // w m_a
 #pragma unroll
         for (int a = 0; a < 10; ++a)
@@ -1330,11 +1339,8 @@ struct ScatteredModel {
         pairs(pairs, std::integral_constant<int, 0>{});
         __syncthreads(); // block == one wave: the totals written above are read by the group's other lanes below
         if (fit) {
-          double f4[4];
-          if (solve10_parked(area, f4) == 0) {
-#pragma unroll
-            for (int s = 0; s < 4; ++s) fi.v[s] = f4[s];
-          }
+          double f1;
+          if (solve10_parked(area, sub & 3, f1) == 0) fi.v[0] = fi.v[1] = fi.v[2] = fi.v[3] = f1; // (this lane's species only)
         }
         __syncthreads(); // (the area is list space again)
       } else {
@@ -1792,13 +1798,11 @@ struct ScatteredModel {
       // park their four densities, the owner collects the 8 x 4
       {
         SRT_LDS d2_t *park = (SRT_LDS d2_t *)((SRT_LDS double *)lists + LDS_PARK);
-        double val[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) val[s] = (live && s < nspec) ? fm::exp_any(fi.v[s]) : 0.0; // failed fit: fi = 0 -> Ns = 1
-        if ((lane & 7) == 0) {
-          park[2 * g] = d2_t{val[0], val[1]};
-          park[2 * g + 1] = d2_t{val[2], val[3]};
-        }
+        // (lane (g, sub < 4) hands over species sub: one exponential per lane; sf_sums<10> fills only that one)
+        const int sm = lane & 3;
+        const double fm_ = sm == 0 ? fi.v[0] : (sm == 1 ? fi.v[1] : (sm == 2 ? fi.v[2] : fi.v[3]));
+        const double val = (live && sm < nspec) ? fm::exp_any(fm_) : 0.0; // failed fit: fi = 0 -> Ns = 1
+        if ((lane & 7) < 4) ((SRT_LDS double *)park)[4 * g + sm] = val;
         __syncthreads();
         if (lane == j) {
 #pragma unroll

@@ -108,18 +108,26 @@ def test_trace_is_the_same_with_and_without_staging(gpu_models):
     from stanford_raytracer_amd import workloads as wl
 
     g = gpu_models["scattered"]
-    pos, d, w = wl.launch_set(256, 31)
+    pos, d, w = wl.launch_set(1024, 31)
     pos = pos * 0.9
     kw = dict(fixedstep=0, dt0=1e-3, dtmax=0.1, tmax=0.05, maxerr=5e-4, maxsteps=60, del_=1e-6, outputper=1)
     ra, na, sa, _ = g.trace(pos, d, w, **kw)
     rb, nb, sb, _ = _own_list(lambda: g.trace(pos, d, w, **kw))
     both = (na > 1) & (nb > 1)
-    assert both.sum() >= 100
+    assert both.sum() >= 400
     assert np.array_equal(ra[both, 0, 1:4], rb[both, 0, 1:4])
     assert vrel(ra[both, 0, 16:20], rb[both, 0, 16:20]).max() <= 1e-12      # densities on the launch row
     assert np.median(vrel(ra[both, 1, 1:4], rb[both, 1, 1:4])) <= 1e-8       # after the first step
-    assert np.mean(sa == sb) >= 0.95
-    assert abs(int(na.sum()) - int(nb.sum())) <= 0.05 * nb.sum()
+    # Fates and row totals: an adaptive launch amplifies rounding (the density gradient is a difference over 1e-6 |x|), so
+    # the yardstick is ONE path against itself with the launch points moved by 1e-13 of their length -- the two paths may
+    # disagree as often as that (twice, plus three standard deviations of a count of 1 024), not by a constant.
+    rc, nc, sc, _ = _own_list(lambda: g.trace(pos * (1.0 + 1e-13), d, w, **kw))
+    yard_fate = float(np.mean(sb != sc))
+    yard_rows = abs(int(nb.sum()) - int(nc.sum())) / nb.sum()
+    n = len(sa)
+    sigma = np.sqrt(max(yard_fate, 1.0 / n) * (1.0 - yard_fate) / n)
+    assert np.mean(sa != sb) <= 2.0 * yard_fate + 3.0 * sigma, (np.mean(sa != sb), yard_fate)
+    assert abs(int(na.sum()) - int(nb.sum())) / nb.sum() <= 2.0 * yard_rows + 0.02, (int(na.sum()), int(nb.sum()), yard_rows)
 
 
 def test_paths_agree_on_the_full_size_sample_set(tmp_path):
