@@ -19,8 +19,13 @@ ARCH = "gfx950"
 
 LIB_SRCS = ["srt_api.hip", "srt_host.cpp", "srt_scattered_host.cpp"]
 CLI_SRCS = ["srt_cli.cpp"]
-HEADERS = ["srt_device.hpp", "srt_models.hpp", "srt_scattered.hpp", "srt_sampler.hpp", "srt_damping.hpp", "srt_t04.hpp", "srt_t04_tables.h", "srt_kernels.hpp", "srt_host.hpp", "tricubic_matrix.h",
-           os.path.join("..", "..", "include", "srt.h")]
+def _headers():
+    """Every header the library is compiled from: all of csrc/*.hpp, csrc/*.h and include/*.h (globbed, so a new header
+    cannot be forgotten: a stale .so under a fresh source hash is what this prevents)."""
+    import glob
+    hs = sorted(glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(CSRC, "*.h")))
+    hs += sorted(glob.glob(os.path.join(PKG, "..", "include", "*.h")))
+    return [os.path.abspath(h) for h in hs]
 
 
 def _hipcc():
@@ -40,7 +45,7 @@ def _stale(target, deps):
 def build(force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(BINDIR, exist_ok=True)
-    deps = [os.path.join(CSRC, f) for f in LIB_SRCS + HEADERS] + [os.path.abspath(__file__)]
+    deps = [os.path.join(CSRC, f) for f in LIB_SRCS] + _headers() + [os.path.abspath(__file__)]
     if force or _stale(LIB, deps):
         cmd = [_hipcc(), "-O3", "--offload-arch=" + ARCH, "-std=c++17", "-fPIC", "-shared", "-o", LIB] + \
               [os.path.join(CSRC, f) for f in LIB_SRCS]

@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/ab_field.sh <variant...> -- the field-option workloads (T04_s, IGRF on config[2]'s set and grid) for library variants, one call
+# tools/scratch/ab_field.sh <variant...> -- the field-option workloads (T04_s, IGRF on config[2]'s set and grid) for library variants, one call
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 for v in "$@"; do
   for w in ${WL:-interp_t04_64k interp_igrf200k}; do

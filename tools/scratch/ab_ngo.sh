@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/ab_ngo.sh <variant...> -- BASELINE config[1] (100k rays, Ngo model) for library variants, two rounds in one call
+# tools/scratch/ab_ngo.sh <variant...> -- BASELINE config[1] (100k rays, Ngo model) for library variants, two rounds in one call
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 for round in 1 2; do
   for v in "$@"; do

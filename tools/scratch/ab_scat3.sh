@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/ab_scat3.sh <variant...> -- config[4] A/B in ONE gpurun call (boxes differ by several %): for every library variant
+# tools/scratch/ab_scat3.sh <variant...> -- config[4] A/B in ONE gpurun call (boxes differ by several %): for every library variant
 # (stanford_raytracer_amd/lib/libsrt_hip_<v>.so, built by tools/ab_build.sh) the scattered825k workload at RAYS rays
 # (default 100000) with the candidate blocks on / off and 8 / 4 waves per CU.  Prints kernel ms and steps/s.
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R

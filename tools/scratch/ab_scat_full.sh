@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/ab_scat_full.sh <variant...> -- config[4] at FULL size (1M rays) for library variants; env MARGINS="0.125 0.08 .." sweeps the
+# tools/scratch/ab_scat_full.sh <variant...> -- config[4] at FULL size (1M rays) for library variants; env MARGINS="0.125 0.08 .." sweeps the
 # candidate blocks' margin (SRT_SCATTERED_MARGIN) for the first variant at 200k rays
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 for m in $MARGINS; do

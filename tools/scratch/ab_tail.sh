@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/ab_tail.sh -- the launch's tail at a strong-scaling shard size (500k rays of config[2]): ray_order 1 (Morton) against 2
+# tools/scratch/ab_tail.sh -- the launch's tail at a strong-scaling shard size (500k rays of config[2]): ray_order 1 (Morton) against 2
 # (likely-short rays last), two rounds in one gpurun call
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 for round in 1 2; do

@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/ab_wl.sh <workload> "<bench args>" variantA variantB ... -- A/B builds of the library on one workload in ONE gpurun call
+# tools/scratch/ab_wl.sh <workload> "<bench args>" variantA variantB ... -- A/B builds of the library on one workload in ONE gpurun call
 set -e
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 WL=$1; ARGS=$2; shift 2

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/dump_lengths.py -- trace the default bench workload once and save every ray's row count and stop code
+"""tools/scratch/dump_lengths.py -- trace the default bench workload once and save every ray's row count and stop code
 (gpurun_out/r02_f/lengths.npz): data for scheduling experiments (which launch parameters predict a long ray)."""
 import os
 import sys

@@ -1,4 +1,4 @@
-"""tools/igrf_det.py -- is the IGRF trace kernel deterministic, and does a library variant change its rows?  (GPU box)"""
+"""tools/scratch/igrf_det.py -- is the IGRF trace kernel deterministic, and does a library variant change its rows?  (GPU box)"""
 import sys
 import numpy as np
 sys.path.insert(0, ".")

@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/pmc_scat.sh <variant...> -- instruction-mix counters of the scattered trace kernel for library variants (A/B)
+# tools/scratch/pmc_scat.sh <variant...> -- instruction-mix counters of the scattered trace kernel for library variants (A/B)
 # env: RAYS (default 100000), WAVES (SRT_WAVES_PER_CU, default unset)
 set -e
 cd /tmp && export TMPDIR=/tmp

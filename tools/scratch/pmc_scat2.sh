@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/pmc_scat2.sh <variant...> -- stall-side counters of the scattered trace kernel (A/B of library variants)
+# tools/scratch/pmc_scat2.sh <variant...> -- stall-side counters of the scattered trace kernel (A/B of library variants)
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R

@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/pmc_scat3.sh <variant...> -- memory-side counters of the scattered trace kernel
+# tools/scratch/pmc_scat3.sh <variant...> -- memory-side counters of the scattered trace kernel
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 RAYS=${RAYS:-100000}

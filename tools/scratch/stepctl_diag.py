@@ -1,4 +1,4 @@
-"""tools/stepctl_diag.py -- where the GPU's first adaptive time stamps leave the oracle's (GPU box; uses the test fixtures' data)"""
+"""tools/scratch/stepctl_diag.py -- where the GPU's first adaptive time stamps leave the oracle's (GPU box; uses the test fixtures' data)"""
 import os, sys, tempfile
 import numpy as np
 sys.path.insert(0, "."); sys.path.insert(0, "tests")

@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/tim_scat.sh <variant...> -- cycle breakdown of coop_stencil (variants built with -DSRT_PHASE_TIMING), 100 k rays
+# tools/scratch/tim_scat.sh <variant...> -- cycle breakdown of coop_stencil (variants built with -DSRT_PHASE_TIMING), 100 k rays
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 for v in "$@"; do
   SRT_PHASE_TIMING=1 SRT_LIB_OVERRIDE=$R/stanford_raytracer_amd/lib/libsrt_hip_$v.so timeout -k 10 300 python bench.py --workload scattered825k --rays 100000 --steps 1 --warmup 0 --cpu-seconds 0 --damping-rays 0 --traffic off --other-configs 0 > gpurun_out/tim_$v.log 2>&1 || exit 1
