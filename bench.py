@@ -294,7 +294,7 @@ def run_workload(ctx, name, steps, warmup, rays_override=0, nstream=1, keep=Fals
     batch = DeviceBatch(model, p, pos0[lo:hi], dir0[lo:hi], w0[lo:hi], dev, nbuf=nstream)
     streams = [torch.cuda.Stream(dev) for _ in range(nstream)] if nstream > 1 else [torch.cuda.current_stream(dev)]
     gather = world > 1 and not args.no_gather
-    pack = lambda rows, nrows: parallel.pack_rows_device(rows, nrows, p.outputper)
+    pack = lambda rows, nrows: parallel.pack_rows_device(rows, nrows, p.outputper, slot=0)  # (one reused buffer: no allocation per step)
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -358,14 +358,15 @@ def run_workload(ctx, name, steps, warmup, rays_override=0, nstream=1, keep=Fals
     if world == 1 and kind == "interp" and steps:
         # the fixed cost the multi-GPU step adds on every rank: packing the kept rows of this launch (srt_pack_rows_device)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        parallel.pack_rows_device(o["rows"], o["nrows"], p.outputper)  # (allocates the reused buffer)
+        parallel.pack_rows_device(o["rows"], o["nrows"], p.outputper, slot=0)  # (allocates the reused buffer)
         torch.cuda.synchronize(dev)
         e0.record()
-        _, off = parallel.pack_rows_device(o["rows"], o["nrows"], p.outputper)
+        _, off = parallel.pack_rows_device(o["rows"], o["nrows"], p.outputper, slot=0)
         e1.record()
         torch.cuda.synchronize(dev)
         res["pack_ms_one_gpu"] = e0.elapsed_time(e1)
         res["packed_bytes_one_gpu"] = int(off[-1]) * 160
+        parallel.release_pack_buffers(dev)
     if world == 1 and kind == "ngo" and steps and hi > lo:
         # what bounds this launch from below: its longest rays alone (<= 8 rays = one wave in tail mode, srt_models.hpp):
         # their sequential attempts x the tail-mode trip time
@@ -421,6 +422,7 @@ def pipelined_pass(ctx, name, rays_override=0, steps=3):
         t = torch.tensor([el], dtype=torch.float64, device=rdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         del batch
+        parallel.release_pack_buffers(dev)
         return {"steps": steps, "ms_per_step": 1e3 * float(t.cpu()[0]) / steps,
                 "note": "parallel.trace_sharded_pipelined: gather of step k overlapped with the trace of step k + 1; "
                         "gather_ms_exposed = this ms_per_step - the trace kernel's time (max over ranks)"}

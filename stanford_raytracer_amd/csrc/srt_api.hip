@@ -61,13 +61,6 @@ extern "C" int srt_init(int device) {
   g_default_device.store(device);
   return SRT_OK;
 }
-static int ensure_init() {
-  int dev = t_device >= 0 ? t_device : g_default_device.load();
-  if (dev < 0) return srt_init(0);
-  if (hipSetDevice(dev) != hipSuccess) return srt_set_error(SRT_EDEVICE, "hipSetDevice(%d) failed", dev);
-  t_device = dev;
-  return SRT_OK;
-}
 // the device the calling thread is bound to right now (srt_init's, or a DeviceScope's)
 static int current_device() {
   int d = -1;
@@ -90,12 +83,42 @@ struct DeviceScope {
     if (hipSetDevice(dev) != hipSuccess) return srt_set_error(SRT_EDEVICE, "hipSetDevice(%d) failed", dev);
     return SRT_OK;
   }
+  // entry points without a model: the thread's srt_init() device (the process default for threads that never called it;
+  // device 0 when nobody did), for the duration of the call only
+  int enter_default() {
+    int dev = t_device >= 0 ? t_device : g_default_device.load();
+    if (dev < 0) {
+      int rc = srt_init(0);
+      if (rc) return rc;
+      dev = 0;
+    }
+    return enter(dev);
+  }
   ~DeviceScope() {
     if (prev >= 0) (void)hipSetDevice(prev);
   }
 };
+// the one device that owns every (non-null) buffer of a device-buffer entry point; -1 + error if one is not device memory or
+// they live on different devices
+static int device_of(const char *who, const void *const *ptrs, int n, int *dev_out) {
+  int dev = -1;
+  for (int i = 0; i < n; ++i) {
+    const void *q = ptrs[i];
+    if (!q) continue;
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, q) != hipSuccess || at.type != hipMemoryTypeDevice) {
+      (void)hipGetLastError();
+      return srt_set_error(SRT_EINVAL, "%s: %p is not device memory", who, q);
+    }
+    if (dev < 0) dev = at.device;
+    else if (at.device != dev) return srt_set_error(SRT_EINVAL, "%s: buffers live on devices %d and %d", who, dev, at.device);
+  }
+  *dev_out = dev;
+  return SRT_OK;
+}
 extern "C" int srt_device_info(char *name, int name_len, int *cu_count, int64_t *hbm_bytes) {
-  int rc = ensure_init();
+  DeviceScope srt_iscope_;
+  int rc = srt_iscope_.enter_default();
   if (rc) return rc;
   hipDeviceProp_t p;
   HIP_OK(hipGetDeviceProperties(&p, current_device()));
@@ -121,10 +144,12 @@ struct srt_model {
   Common *d_common = nullptr;
   int64_t device_bytes = 0;
   int cu_count = 256;
-  // Per-launch scratch, in NSLOT rotating slots so that launches on different streams may overlap (a slot is
-  // reused only after the launch that used it has finished: `done` is waited on by the next user's stream).
+  // Per-launch scratch in NSLOT slots, so that launches on different streams may overlap.  A launch takes a slot whose previous
+  // launch has FINISHED (its `done` event has fired) before it opens a new one: a caller that launches from one stream, one
+  // launch after the other, lives in a single slot (scattered model: 9.7 GB of candidate blocks + staging per slot at grid 2048),
+  // and only launches that really overlap occupy more.  When every slot is busy the next one in turn is waited for.
   struct LaunchSlot {
-    hipEvent_t ev0 = nullptr, ev1 = nullptr; // around the launch: srt_last_kernel_ms
+    hipEvent_t done = nullptr; // recorded behind the launch that used this slot's scratch last
     bool used = false;
     // ray_order option (grow-only): keys in/out, ids in/out, radix-sort workspace
     unsigned *d_keys[2] = {nullptr, nullptr};
@@ -133,14 +158,23 @@ struct srt_model {
     size_t sort_cap = 0, sorttmp_bytes = 0;
     // scattered model (grow-only): staging records of coop_stencil, REC_CAP * REC doubles per one-wave block
     double *d_stage = nullptr;
-    long long stage_blocks = 0;
+    long long stage_blocks = 0, stage_failed = 0; // (failed: the grid size whose allocation was refused -- not retried per launch)
     // scattered model (grow-only): the lanes' candidate blocks, BLOCK_DOUBLES per one-wave block
     double *d_blocks = nullptr;
-    long long cand_blocks = 0;
+    long long cand_blocks = 0, cand_failed = 0;
   };
   static constexpr int NSLOT = 4;
   LaunchSlot slot[NSLOT];
-  int next_slot = 0, last_slot = -1;
+  int rr_slot = 0;
+  // timing history of the last NHIST launches (srt_last_kernel_ms, srt_launch_ms), its own ring: slots are reused out of turn
+  struct LaunchTimes {
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool used = false;
+  };
+  static constexpr int NHIST = 4;
+  LaunchTimes hist[NHIST];
+  int next_hist = 0, last_hist = -1;
+  bool warned_scratch = false;
   // device staging of the host-buffer entry point srt_trace_batch (grow-only, freed with the model): the CLI calls it
   // once per chunk of the ray file, and a fresh hipMalloc / hipFree of gigabytes per call costs as much as a small launch
   struct HostIO {
@@ -209,9 +243,10 @@ static int model_finish(srt_model *m) {
   m->device = current_device();
   HIP_OK(hipGetDeviceProperties(&p, m->device));
   m->cu_count = p.multiProcessorCount;
-  for (auto &sl : m->slot) {
-    HIP_OK(hipEventCreate(&sl.ev0));
-    HIP_OK(hipEventCreate(&sl.ev1));
+  for (auto &sl : m->slot) HIP_OK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+  for (auto &h : m->hist) {
+    HIP_OK(hipEventCreate(&h.ev0));
+    HIP_OK(hipEventCreate(&h.ev1));
   }
   return SRT_OK;
 }
@@ -233,8 +268,11 @@ extern "C" void srt_model_destroy(srt_model *m) {
     if (sl.d_sorttmp) (void)hipFree(sl.d_sorttmp);
     if (sl.d_stage) (void)hipFree(sl.d_stage);
     if (sl.d_blocks) (void)hipFree(sl.d_blocks);
-    if (sl.ev0) (void)hipEventDestroy(sl.ev0);
-    if (sl.ev1) (void)hipEventDestroy(sl.ev1);
+    if (sl.done) (void)hipEventDestroy(sl.done);
+  }
+  for (auto &h : m->hist) {
+    if (h.ev0) (void)hipEventDestroy(h.ev0);
+    if (h.ev1) (void)hipEventDestroy(h.ev1);
   }
   if (m->d_common) (void)hipFree(m->d_common);
   for (void *q : m->io.p)
@@ -248,7 +286,7 @@ extern "C" int srt_model_trim(srt_model *m) {
   if (rc) return rc;
   std::lock_guard<std::mutex> hold(m->io_lock);
   for (auto &sl : m->slot) {
-    if (sl.used) HIP_OK(hipEventSynchronize(sl.ev1)); // the launch that used this slot's scratch is over
+    if (sl.used) HIP_OK(hipEventSynchronize(sl.done)); // the launch that used this slot's scratch is over
     for (int k = 0; k < 2; ++k) {
       if (sl.d_keys[k]) (void)hipFree(sl.d_keys[k]);
       if (sl.d_ids[k]) (void)hipFree(sl.d_ids[k]);
@@ -263,6 +301,7 @@ extern "C" int srt_model_trim(srt_model *m) {
     sl.d_blocks = nullptr;
     sl.sort_cap = sl.sorttmp_bytes = 0;
     sl.stage_blocks = sl.cand_blocks = 0;
+    sl.stage_failed = sl.cand_failed = 0;
   }
   for (int k = 0; k < 9; ++k) {
     if (m->io.p[k]) (void)hipFree(m->io.p[k]);
@@ -340,7 +379,8 @@ __global__ void ngo_norm_kernel(NgoModel g, double z1, double sinz22, double lat
 
 extern "C" int srt_model_create_ngo(const char *configfile, int yearday, int msec, srt_model **out) {
   if (!configfile || !out) return srt_set_error(SRT_EINVAL, "null argument");
-  int rc = ensure_init();
+  DeviceScope srt_iscope_;
+  int rc = srt_iscope_.enter_default();
   if (rc) return rc;
   srt_host::NgoConfig cfg;
   std::string err;
@@ -589,7 +629,8 @@ extern "C" int srt_model_create_interp(int nspec, int nx, int ny, int nz, const 
   if (nspec < 1 || nspec > SRT_MAXSPEC)
     return srt_set_error(SRT_EINVAL, "nspec=%d unsupported (1..%d species: SRT_MAXSPEC, include/srt.h)", nspec, SRT_MAXSPEC);
   if (nx < 2 || ny < 2 || nz < 2) return srt_set_error(SRT_EINVAL, "grid must have >= 2 nodes per axis");
-  int rc = ensure_init();
+  DeviceScope srt_iscope_;
+  int rc = srt_iscope_.enter_default();
   if (rc) return rc;
   const size_t n = (size_t)nx * ny * nz * nspec;
   if ((size_t)(nx + 1) * (ny + 1) * (nz + 1) >= (size_t)1 << 31) return srt_set_error(SRT_EINVAL, "grid too large");
@@ -794,7 +835,8 @@ extern "C" int srt_model_create_scattered_file(const char *ptsfile, int yearday,
     return srt_set_error(SRT_EINVAL, "scattered_interp_order=%d: orders 0..3 are supported (the reference's generate_monomials orders, "
                                      "N >= 4, are not built: stay on the Fortran path for them)", order);
   if (!(window_scale > 0) || !(local_window_scale > 0)) return srt_set_error(SRT_EINVAL, "window scales must be > 0");
-  int rc = ensure_init();
+  DeviceScope srt_iscope_;
+  int rc = srt_iscope_.enter_default();
   if (rc) return rc;
   srt_host::ScatteredHost h;
   std::string err;
@@ -864,6 +906,15 @@ struct DevBuf {
   int alloc(size_t n) { return hipMalloc(&p, n * sizeof(double)) == hipSuccess ? 0 : -1; }
 };
 
+// a scratch allocation of the scattered model was refused: say so ONCE per model (the launch still runs -- without staging
+// every stencil takes the own-list path, without blocks every stencil scans its cells -- only slower), and do not try that
+// size again at every launch (LaunchSlot::*_failed; srt_model_trim forgets it)
+static void scratch_refused(srt_model *m, const char *what, size_t bytes) {
+  if (m->warned_scratch) return;
+  m->warned_scratch = true;
+  fprintf(stderr, "libsrt_hip: hipMalloc of %.2f GB for the scattered model's %s was refused; tracing without them (slower). "
+                  "srt_model_trim() on this or other models releases launch scratch.\n", (double)bytes / 1e9, what);
+}
 // SRT_SCATTERED_STAGING=0 in the environment: no staging buffer, i.e. the own-list path for every stencil (tests hold
 // the two paths against each other)
 static bool staging_enabled() {
@@ -946,7 +997,8 @@ extern "C" int srt_dispersion(srt_model *m, int64_t n, const double *x, const do
 extern "C" int srt_is_right_handed(int64_t n, const double *in, int32_t *out) {
   if (!in || !out || n < 0) return srt_set_error(SRT_EINVAL, "bad argument");
   if (n == 0) return SRT_OK;
-  int rc = ensure_init();
+  DeviceScope srt_iscope_;
+  int rc = srt_iscope_.enter_default();
   if (rc) return rc;
   DevBuf din;
   if ((rc = upload(din, in, 5 * n))) return rc;
@@ -1257,7 +1309,7 @@ __device__ __forceinline__ unsigned spread3(unsigned v) { // 0b abc -> 0b a00b00
   return v;
 }
 // two_class (ray_order = 2, an experiment switch: DESIGN section 9): rays that are likely to stop early -- above 6 kHz and
-// launched inwards: 8.5 % of the BASELINE launch set, mean 75 rows against 197 -- sort behind all others (key bit 27)
+// launched inwards: 8.5 % of the BASELINE launch set, mean 75 rows against 197 -- sort behind all others (key bit 30: above the Morton code, 10 bits per axis = bits 0..29)
 __global__ void ray_keys_kernel(const InterpModel *mp, const double *pos0 /* SoA [3][n] */, const double *dir0, const double *w0,
                                 int two_class, long long n, unsigned *keys, int *ids) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1269,7 +1321,7 @@ __global__ void ray_keys_kernel(const InterpModel *mp, const double *pos0 /* SoA
   unsigned key = spread3(ci) | (spread3(cj) << 1) | (spread3(ck) << 2);
   if (two_class) {
     const bool inward = dir0[i] * x + dir0[n + i] * y + dir0[2 * n + i] * z < 0.0;
-    if (inward && w0[i] > 2.0 * PI * 6.0e3) key |= 1u << 27;
+    if (inward && w0[i] > 2.0 * PI * 6.0e3) key |= 1u << 30;
   }
   keys[i] = key;
   ids[i] = (int)i;
@@ -1324,14 +1376,31 @@ extern "C" int srt_trace_batch_device(srt_model *m, const srt_params *p, int64_t
   long long want = (nrays + cap - 1) / cap;
   if (grid > want) grid = want;
   if (grid < 1) grid = 1;
-  srt_model::LaunchSlot &sl = m->slot[m->next_slot];
-  if (sl.used) HIP_OK(hipStreamWaitEvent(st, sl.ev1, 0)); // the slot's previous launch (maybe on another stream) is over
-  HIP_OK(hipEventRecord(sl.ev0, st));
+  // scratch slot: one whose last launch is over (preferring one that holds buffers already), else a fresh one, else -- all
+  // busy -- the next in turn, which this stream then waits for
+  int si = -1;
+  for (int k = 0; k < srt_model::NSLOT && si < 0; ++k)
+    if (m->slot[k].used) {
+      const hipError_t q = hipEventQuery(m->slot[k].done);
+      if (q == hipSuccess) si = k;
+      else if (q != hipErrorNotReady) HIP_OK(q);
+      else (void)hipGetLastError();
+    }
+  for (int k = 0; k < srt_model::NSLOT && si < 0; ++k)
+    if (!m->slot[k].used) si = k;
+  if (si < 0) {
+    si = m->rr_slot;
+    m->rr_slot = (m->rr_slot + 1) % srt_model::NSLOT;
+  }
+  srt_model::LaunchSlot &sl = m->slot[si];
+  if (sl.used) HIP_OK(hipStreamWaitEvent(st, sl.done, 0)); // the slot's previous launch (maybe on another stream) is over
+  srt_model::LaunchTimes &lt = m->hist[m->next_hist];
+  HIP_OK(hipEventRecord(lt.ev0, st));
   if (p->ray_order >= 1 && m->kind == 3 && nrays > WAVE && nrays < (1ll << 31) && m->interp.ax.n < 1023 &&
       m->interp.ay.n < 1023 && m->interp.az.n < 1023) {
     // work through the launch set in the order of the rays' launch cells (inside the timed region)
     if ((size_t)nrays > sl.sort_cap) {
-      if (sl.used) HIP_OK(hipEventSynchronize(sl.ev1)); // about to free what that launch may still read
+      if (sl.used) HIP_OK(hipEventSynchronize(sl.done)); // about to free what that launch may still read
       for (int k = 0; k < 2; ++k) {
         if (sl.d_keys[k]) (void)hipFree(sl.d_keys[k]);
         if (sl.d_ids[k]) (void)hipFree(sl.d_ids[k]);
@@ -1346,9 +1415,9 @@ extern "C" int srt_trace_batch_device(srt_model *m, const srt_params *p, int64_t
       sl.sort_cap = (size_t)nrays;
     }
     size_t need = 0;
-    HIP_OK(hipcub::DeviceRadixSort::SortPairs(nullptr, need, sl.d_keys[0], sl.d_keys[1], sl.d_ids[0], sl.d_ids[1], (int)nrays, 0, 30, st));
+    HIP_OK(hipcub::DeviceRadixSort::SortPairs(nullptr, need, sl.d_keys[0], sl.d_keys[1], sl.d_ids[0], sl.d_ids[1], (int)nrays, 0, 31, st));
     if (need > sl.sorttmp_bytes) {
-      if (sl.used) HIP_OK(hipEventSynchronize(sl.ev1));
+      if (sl.used) HIP_OK(hipEventSynchronize(sl.done));
       if (sl.d_sorttmp) (void)hipFree(sl.d_sorttmp);
       sl.d_sorttmp = nullptr;
       sl.sorttmp_bytes = 0;
@@ -1358,32 +1427,42 @@ extern "C" int srt_trace_batch_device(srt_model *m, const srt_params *p, int64_t
     hipLaunchKernelGGL(ray_keys_kernel, dim3((unsigned)((nrays + 255) / 256)), dim3(256), 0, st, (const InterpModel *)m->d_model,
                        d_pos0, d_dir0, d_w0, p->ray_order == 2 ? 1 : 0, (long long)nrays, sl.d_keys[0], sl.d_ids[0]);
     size_t tb = sl.sorttmp_bytes;
-    HIP_OK(hipcub::DeviceRadixSort::SortPairs(sl.d_sorttmp, tb, sl.d_keys[0], sl.d_keys[1], sl.d_ids[0], sl.d_ids[1], (int)nrays, 0, 30, st));
+    HIP_OK(hipcub::DeviceRadixSort::SortPairs(sl.d_sorttmp, tb, sl.d_keys[0], sl.d_keys[1], sl.d_ids[0], sl.d_ids[1], (int)nrays, 0, 31, st));
     a.order = sl.d_ids[1];
   }
   a.scratch = nullptr;
   if (m->kind == 4 && staging_enabled()) { // without the buffer the kernel still runs (own-list path everywhere), only slower
-    if (grid > sl.stage_blocks) {
-      if (sl.used) HIP_OK(hipEventSynchronize(sl.ev1));
+    if (grid > sl.stage_blocks && !(sl.stage_failed > 0 && grid >= sl.stage_failed)) {
+      if (sl.used) HIP_OK(hipEventSynchronize(sl.done));
       if (sl.d_stage) (void)hipFree(sl.d_stage);
       sl.d_stage = nullptr;
       sl.stage_blocks = 0;
-      if (hipMalloc(&sl.d_stage, (size_t)grid * ScatteredModel::REC_CAP * ScatteredModel::REC * sizeof(double)) == hipSuccess) sl.stage_blocks = grid;
-      else (void)hipGetLastError();
+      const size_t bytes = (size_t)grid * ScatteredModel::REC_CAP * ScatteredModel::REC * sizeof(double);
+      if (hipMalloc(&sl.d_stage, bytes) == hipSuccess) sl.stage_blocks = grid;
+      else {
+        (void)hipGetLastError();
+        sl.stage_failed = grid;
+        scratch_refused(m, "staging records", bytes);
+      }
     }
-    a.scratch = sl.d_stage;
+    a.scratch = grid <= sl.stage_blocks ? sl.d_stage : nullptr;
   }
   a.scratch2 = nullptr;
   if (m->kind == 4 && a.scratch != nullptr && blocks_enabled()) { // without them the kernel scans the cells for every stencil
-    if (grid > sl.cand_blocks) {
-      if (sl.used) HIP_OK(hipEventSynchronize(sl.ev1));
+    if (grid > sl.cand_blocks && !(sl.cand_failed > 0 && grid >= sl.cand_failed)) {
+      if (sl.used) HIP_OK(hipEventSynchronize(sl.done));
       if (sl.d_blocks) (void)hipFree(sl.d_blocks);
       sl.d_blocks = nullptr;
       sl.cand_blocks = 0;
-      if (hipMalloc(&sl.d_blocks, (size_t)grid * ScatteredModel::BLOCK_DOUBLES * sizeof(double)) == hipSuccess) sl.cand_blocks = grid;
-      else (void)hipGetLastError();
+      const size_t bytes = (size_t)grid * ScatteredModel::BLOCK_DOUBLES * sizeof(double);
+      if (hipMalloc(&sl.d_blocks, bytes) == hipSuccess) sl.cand_blocks = grid;
+      else {
+        (void)hipGetLastError();
+        sl.cand_failed = grid;
+        scratch_refused(m, "candidate blocks", bytes);
+      }
     }
-    a.scratch2 = sl.d_blocks;
+    a.scratch2 = grid <= sl.cand_blocks ? sl.d_blocks : nullptr;
   }
   const bool fixed = p->fixedstep != 0;
   const int fopt = m->cm.fld.use_tsy != 0 ? 2 : (m->cm.fld.use_igrf != 0 ? 1 : 0);
@@ -1409,7 +1488,8 @@ extern "C" int srt_trace_batch_device(srt_model *m, const srt_params *p, int64_t
 #undef SRT_LAUNCH_TRACE
 #undef SRT_LAUNCH_TRACE1
   HIP_OK(hipGetLastError());
-  HIP_OK(hipEventRecord(sl.ev1, st));
+  HIP_OK(hipEventRecord(lt.ev1, st));
+  HIP_OK(hipEventRecord(sl.done, st));
 #ifdef SRT_TRIP_TIMING
   if (getenv("SRT_TRIP_TIMING")) {
     unsigned long long h[16];
@@ -1435,7 +1515,7 @@ extern "C" int srt_trace_batch_device(srt_model *m, const srt_params *p, int64_t
     unsigned long long ws[4];
     float ms = 0.f;
     HIP_OK(hipMemcpyFromSymbol(ws, HIP_SYMBOL(srt_wave_stats), sizeof ws));
-    HIP_OK(hipEventElapsedTime(&ms, sl.ev0, sl.ev1));
+    HIP_OK(hipEventElapsedTime(&ms, lt.ev0, lt.ev1));
     // (the timers of the eight XCDs are not aligned with each other: only a wave's own span means something)
     fprintf(stderr, "srt wave stats: grid %lld, working waves %llu, launch %.1f ms, mean span of a working wave %.4g ticks = %.1f MHz if it ran for the whole launch\n",
             grid, ws[0], ms, ws[0] ? (double)ws[1] / (double)ws[0] : 0.0, ws[0] ? (double)ws[1] / (double)ws[0] / (ms * 1e3) : 0.0);
@@ -1444,29 +1524,26 @@ extern "C" int srt_trace_batch_device(srt_model *m, const srt_params *p, int64_t
   }
 #endif
   sl.used = true;
-  m->last_slot = m->next_slot;
-  m->next_slot = (m->next_slot + 1) % srt_model::NSLOT;
+  lt.used = true;
+  m->last_hist = m->next_hist;
+  m->next_hist = (m->next_hist + 1) % srt_model::NHIST;
   return SRT_OK;
 }
 
 extern "C" int srt_launch_ms(srt_model *m, int back, float *ms) {
   if (!m || !ms) return srt_set_error(SRT_EINVAL, "null argument");
-  if (back < 0 || back >= srt_model::NSLOT || m->last_slot < 0) return srt_set_error(SRT_EINVAL, "no such launch");
-  srt_model::LaunchSlot &sl = m->slot[(m->last_slot - back + srt_model::NSLOT) % srt_model::NSLOT];
-  if (!sl.used) return srt_set_error(SRT_EINVAL, "no such launch");
-  HIP_OK(hipEventSynchronize(sl.ev1));
-  HIP_OK(hipEventElapsedTime(ms, sl.ev0, sl.ev1));
+  if (back < 0 || back >= srt_model::NHIST || m->last_hist < 0) return srt_set_error(SRT_EINVAL, "no such launch");
+  srt_model::LaunchTimes &lt = m->hist[(m->last_hist - back + srt_model::NHIST) % srt_model::NHIST];
+  if (!lt.used) return srt_set_error(SRT_EINVAL, "no such launch");
+  SRT_MODEL_SCOPE;
+  int rc = ensure_model(m);
+  if (rc) return rc;
+  HIP_OK(hipEventSynchronize(lt.ev1));
+  HIP_OK(hipEventElapsedTime(ms, lt.ev0, lt.ev1));
   return SRT_OK;
 }
 
-extern "C" int srt_last_kernel_ms(srt_model *m, float *ms) {
-  if (!m || !ms) return srt_set_error(SRT_EINVAL, "null argument");
-  if (m->last_slot < 0) return srt_set_error(SRT_EINVAL, "no trace launched on this model yet");
-  srt_model::LaunchSlot &sl = m->slot[m->last_slot];
-  HIP_OK(hipEventSynchronize(sl.ev1));
-  HIP_OK(hipEventElapsedTime(ms, sl.ev0, sl.ev1));
-  return SRT_OK;
-}
+extern "C" int srt_last_kernel_ms(srt_model *m, float *ms) { return srt_launch_ms(m, 0, ms); }
 
 
 // ---- the step after the path: hot-plasma damping along the kept rows (kernels: srt_damping.hpp) ----
@@ -1482,9 +1559,15 @@ extern "C" int srt_damping_device(const srt_damping_params *dp, int nspec, const
   if (dp->nres < 0 || dp->nres > DMP_MAXRES) return srt_set_error(SRT_EINVAL, "nres out of range (0..%d)", DMP_MAXRES);
   if (dp->dist == 1 && (!(dp->kT > 0.0) || !(dp->Ne_h >= 0.0))) return srt_set_error(SRT_EINVAL, "Maxwell-Boltzmann needs kT > 0 and Ne_h >= 0");
   if (!(dp->tol >= 0.0)) return srt_set_error(SRT_EINVAL, "tol must be >= 0");
-  int rc = ensure_init();
-  if (rc) return rc;
   if (nrays == 0) return SRT_OK;
+  // the work goes to the device that owns the buffers (as srt_pack_rows_device), for the duration of the call
+  int dev = -1, rc;
+  {
+    const void *ptrs[6] = {d_rows, d_nrows, d_w0, d_rate, d_magnitude, d_flag};
+    if ((rc = device_of("srt_damping_device", ptrs, 6, &dev))) return rc;
+  }
+  DeviceScope scope;
+  if ((rc = scope.enter(dev))) return rc;
   if (nrays * (long long)slots >= (1ll << 40)) return srt_set_error(SRT_EINVAL, "too many rows");
   DampArgs a;
   a.rows = d_rows;
@@ -1524,7 +1607,8 @@ extern "C" int srt_damping(const srt_damping_params *dp, int nspec, const double
                            int32_t outputper, int64_t nrays, const double *rows, const int32_t *nrows, const double *w0,
                            double *rate, double *magnitude, int32_t *flag) {
   if (!rows || !nrows || !w0 || !rate || nrays < 0 || slots < 1) return srt_set_error(SRT_EINVAL, "bad argument");
-  int rc = ensure_init();
+  DeviceScope srt_iscope_;
+  int rc = srt_iscope_.enter_default();
   if (rc) return rc;
   if (nrays == 0) return SRT_OK;
   const size_t nr = (size_t)nrays * slots;
@@ -1587,24 +1671,14 @@ extern "C" int srt_pack_rows_device(int32_t slots, int32_t outputper, int64_t nr
     return srt_set_error(SRT_EINVAL, "bad argument");
   // The work goes to the device that OWNS the buffers (not to whatever device the calling thread happens to be bound to):
   // a process may drive several GPUs from one thread.  All buffers must live on one device.
-  int dev = -1;
+  int dev = -1, rc;
   {
     const void *ptrs[4] = {d_offsets, nrays > 0 ? (const void *)d_rows : nullptr, nrays > 0 ? (const void *)d_nrows : nullptr,
                            nrays > 0 && capacity_rows > 0 ? (const void *)d_packed : nullptr};
-    for (const void *q : ptrs) {
-      if (!q) continue;
-      hipPointerAttribute_t at;
-      if (hipPointerGetAttributes(&at, q) != hipSuccess || at.type != hipMemoryTypeDevice) {
-        (void)hipGetLastError();
-        return srt_set_error(SRT_EINVAL, "srt_pack_rows_device: %p is not device memory", q);
-      }
-      if (dev < 0) dev = at.device;
-      else if (at.device != dev) return srt_set_error(SRT_EINVAL, "srt_pack_rows_device: buffers live on devices %d and %d", dev, at.device);
-    }
+    if ((rc = device_of("srt_pack_rows_device", ptrs, 4, &dev))) return rc;
   }
   DeviceScope scope;
-  int rc = scope.enter(dev);
-  if (rc) return rc;
+  if ((rc = scope.enter(dev))) return rc;
   hipStream_t st = (hipStream_t)stream;
   if (nrays == 0) {
     HIP_OK(hipMemsetAsync(d_offsets, 0, sizeof(int64_t), st));

@@ -39,6 +39,23 @@ __device__ __forceinline__ double sqrt_pos(double x) {
   g = fma(d, h, g);
   return x == 0.0 ? 0.0 : g;
 }
+// g = sqrt(x) and inv = 1 / g for a positive normal x from ONE v_rsq_f64: the Goldschmidt pair (g, h = 1 / (2 g)) of sqrt_pos,
+// then one Newton step on 2 h against the finished g (<= 1 ulp each; 13 operations against sqrt_pos + fdiv's 20)
+__device__ __forceinline__ void sqrt_and_inv_pos(double x, double &g_out, double &inv_out) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  const double r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  double d = fma(-g, g, x);
+  g = fma(d, h, g);
+  d = fma(-g, g, x);
+  g = fma(d, h, g);
+  double inv = h + h;
+  inv = fma(fma(-g, inv, 1.0), inv, inv);
+  g_out = g;
+  inv_out = inv;
+}
 // sin and cos of a in [0, pi (1 + 2e-3)]: quadrant k = 0, 1, 2, t = a - k pi/2 in about [-pi/4, pi/4]
 __device__ __forceinline__ void sincos_0pi(double a, double &s, double &c) {
   const double PIO2_HI = 1.57079632673412561417e+00, PIO2_LO = 6.07710050650619224932e-11; // k * hi is exact (33 bits)

@@ -677,7 +677,8 @@ struct ScatteredModel {
 #pragma unroll
       for (int l = 0; l < j; ++l) s -= at(l, j) * at(l, j);
       if (!(s > 0.0)) return 1;
-      const double ujj = fm::sqrt_pos(s), inv = fdiv(1.0, ujj); // (a positive pivot of sums of squares of O(1) offsets: normal range)
+      double ujj, inv; // (a positive pivot of sums of squares of O(1) offsets: normal range)
+      fm::sqrt_and_inv_pos(s, ujj, inv);
       at(j, j) = ujj;
       rinv[j] = inv;
 #pragma unroll
@@ -810,6 +811,7 @@ struct ScatteredModel {
   struct Pass1Out {
     double hin8[8];
     int cnt8[8];
+    int kept8[8]; // written by sf_weights: samples of the point's window that stay above the weight mask (:316-317)
   };
   __device__ __forceinline__ static SRT_LDS Pass1Out *pass1_out(SRT_LDS const int *list) {
     return (SRT_LDS Pass1Out *)((SRT_LDS double *)const_cast<SRT_LDS int *>(list) + LDS_PARK);
@@ -1010,10 +1012,11 @@ struct ScatteredModel {
   }
 
   // All eight half-weights of every sample of the list (see above); usemask: the reference's weight > 1e-16 mask (:316-317)
+  // padded_len: records [n_list, padded_len) get zero weights (the pair loop reads whole chunks and tests no index)
   template <int J>
   __device__ __forceinline__ void sf_weights(const double (&p_in)[3], bool live, unsigned long long livemask, int npts, int n_list,
                                           SRT_LDS const int *list, double *rec_flat, double dmax6, double d7, bool p7near,
-                                          bool usemask) const {
+                                          bool usemask, int padded_len) const {
     const ScatteredModel M = uniform_copy();
     const double p[3] = {p_in[0], p_in[1], p_in[2]};
     const double radius = M.radius;
@@ -1021,9 +1024,10 @@ struct ScatteredModel {
     const int lane = threadIdx.x, g = lane >> 3;
     const double r2 = radius * radius, pi_R = PI / radius, reps = radius * 5.0e-16;
     SRT_PHASE_BEGIN(list);
-    SRT_LDS const Pass1Out *o = pass1_out(list);
+    SRT_LDS Pass1Out *o = pass1_out(list);
     double hin8[8], pg[8][3];
     bool fit8[8], lv8[8];
+    int kept_c[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // wave-uniform: samples that keep a non-zero weight at point g
 #pragma unroll
     for (int gg = 0; gg < 8; ++gg) {
       hin8[gg] = uni(o->hin8[gg]);
@@ -1153,6 +1157,10 @@ struct ScatteredModel {
       *chunk(rec, 5, k) = d2_t{w8[2], w8[3]};
       *chunk(rec, 6, k) = d2_t{w8[4], w8[5]};
       *chunk(rec, 7, k) = d2_t{w8[6], w8[7]};
+      // (one compare per point and sample here instead of a compare + add per (point, neighbour) in the pair loop; the count
+      // itself is scalar arithmetic)
+#pragma unroll
+      for (int gg = 0; gg < 8; ++gg) kept_c[gg] += __popcll(__ballot(w8[gg] != 0.0));
     };
     // the samples whose {x, y, z, r_c, cos, sin} wait in LDS: no load from device memory in this loop, so nothing in it ever
     // waits for the previous trip's stores
@@ -1165,14 +1173,45 @@ struct ScatteredModel {
       const d2_t c0 = *chunk(rec, 0, k), c1 = *chunk(rec, 1, k), c4 = *chunk(rec, 4, k), c5 = *chunk(rec, 5, k);
       weigh(k, c0, d2_t{c1.x, c4.x}, c5);
     }
+#pragma unroll 1
+    for (int k = n_list + lane; k < padded_len; k += 64) {
+      const d2_t z = {0.0, 0.0};
+      *chunk(rec, 4, k) = z;
+      *chunk(rec, 5, k) = z;
+      *chunk(rec, 6, k) = z;
+      *chunk(rec, 7, k) = z;
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int gg = 0; gg < 8; ++gg) o->kept8[gg] = kept_c[gg];
+    }
     __syncthreads(); // block == one wave: the weights written above are read by other lanes next
     SRT_PHASE(3);
   }
 
-  // Normal equations of this group's point from the finished records, and the solve
+  // The pair loop's split of a stencil's records over the lanes.  8 points (the end-point stencil): group g = point g, its 8
+  // lanes take records 8 i + sub of a 64-record chunk.  7 points (every evalrhs stencil): group 7 has no point, so its lane h
+  // HELPS point h -- 9 lanes per point, records 9 i + (sub | 8 for the helper) of a 63-record chunk, 7 iterations per chunk
+  // instead of 8 -- and hands its partial sums to group h through LDS before the group reductions (lane 63 idles).
+  struct PairSplit {
+    bool nine;
+    int per, iters, nchunk, padded;
+    __device__ __forceinline__ PairSplit(int npts, int n_list) {
+#ifndef SRT_SCAT_NINE
+#define SRT_SCAT_NINE 1 // (0: the 8-way split for every stencil, for A/B)
+#endif
+      nine = SRT_SCAT_NINE != 0 && npts == 7;
+      per = nine ? 63 : 64;
+      iters = nine ? 7 : 8;
+      nchunk = (n_list + per - 1) / per;
+      padded = nchunk * per + (64 - per); // (the DMA of a chunk moves 64 records)
+    }
+  };
+  // Normal equations of this group's point from the finished records, and the solve.  p_in / fit: of the point this lane sums
+  // for (a helper lane's: its point's, see PairSplit).
   template <int J>
   __device__ __noinline__ Fit4 sf_sums(const double (&p_in)[3], bool fit, int n_list, SRT_LDS const int *list, double *rec_flat,
-                                       int &kept_out) const {
+                                       const PairSplit ps) const {
     Fit4 fi;
     const double p[3] = {p_in[0], p_in[1], p_in[2]}; // in registers: the asm statements below clobber memory
     SRT_AS1 double *const rec = (SRT_AS1 double *)rec_flat;
@@ -1183,7 +1222,6 @@ struct ScatteredModel {
     double A[(O3 || J == 10) ? 1 : NT], b[O3 ? 1 : J][4];
     double Mm[J == 10 ? Moments::N : 1]; // order 2: the 35 moments stand in for the 55 entries of A while summing
     typename std::conditional<O3, Sums20, int>::type S20;
-    int kept = 0;
     if constexpr (O3) S20.zero();
 #pragma unroll
     for (int t = 0; t < ((O3 || J == 10) ? 1 : NT); ++t) A[t] = 0.0;
@@ -1227,28 +1265,62 @@ struct ScatteredModel {
         }
       }
     };
+    // every running sum of this lane, in one fixed order (the helpers' hand-over below)
+    auto each_sum = [&](auto f) {
+      if constexpr (O3) {
+#pragma unroll
+        for (int t = 0; t < MomentsT<3>::N; ++t) f(S20.Mm[t], t);
+#pragma unroll
+        for (int a = 0; a < 20; ++a)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) f(S20.b[a][s], MomentsT<3>::N + 4 * a + s);
+      } else {
+        constexpr int NA = J == 10 ? Moments::N : NT;
+        if constexpr (J == 10) {
+#pragma unroll
+          for (int t = 0; t < NA; ++t) f(Mm[t], t);
+        } else {
+#pragma unroll
+          for (int t = 0; t < NA; ++t) f(A[t], t);
+        }
+#pragma unroll
+        for (int a = 0; a < J; ++a)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) f(b[a][s], NA + 4 * a + s);
+      }
+    };
+    constexpr int NSUM = O3 ? MomentsT<3>::N + 80 : (J == 10 ? Moments::N : NT) + 4 * J;
+    constexpr int HELP_OFF = 700; // doubles into the list area: behind the parked totals of order 2 (8 x 80)
+    static_assert(HELP_OFF + 7 * NSUM <= LIST_DOUBLES && HELP_OFF >= 8 * 80, "the helpers' hand-over must fit the list area");
     // The records come back through a ring of NBUF 64-record buffers in LDS (the list area: the list is dead by now),
     // filled by LDS-DMA NBUF - 1 buffers ahead -- the staging buffers of the CU's waves do not stay in L2 (the scans of
     // the other waves stream through it).
     // Buffer layout: [16-byte chunk t of the record][record] -- DMA instruction t moves chunk t of 64 records (lane =
-    // record), and the 8 lanes of a group read 8 neighbouring 16-byte slots (all 8 groups the same ones: broadcast).
+    // record), and the lanes of a group read neighbouring 16-byte slots (all groups the same ones: broadcast).
+    // No index test and no count in the loop: the records behind the list carry zero weights (sf_weights; their x, y, z,
+    // ln N are the last record's: finite), and what survives the weight mask was counted there.
     {
-      const int nchunk = (n_list + 63) >> 6; // wave-uniform
+      // (wave-uniform, but arguments of an out-of-line function arrive in vector registers: back to scalars)
+      const int nchunk = uni(ps.nchunk), per = uni(ps.per), iters = uni(ps.iters);
       SRT_AS3 char *const ring = (SRT_AS3 char *)list;
       auto issue = [&](int c) {
-        int r = c * 64 + lane;
-        r = r < n_list ? r : n_list - 1;
+        const int r = c * per + lane;
+        const int rc = r < n_list ? r : n_list - 1;
         SRT_AS3 char *dst = ring + (c % NBUF) * 8192;
 #pragma unroll
         for (int t = 0; t < 8; ++t) // (chunk-major staging: instruction t reads 1 KiB of consecutive bytes)
-          __builtin_amdgcn_global_load_lds((const SRT_AS1 void *)chunk(rec, t, r), (SRT_AS3 void *)(dst + 1024 * t), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((const SRT_AS1 void *)chunk(rec, t, t < 4 ? rc : r), (SRT_AS3 void *)(dst + 1024 * t), 16, 0, 0);
       };
       const bool any = __any(fit);
       if (any) {
         for (int c = 0; c < NBUF - 1 && c < nchunk; ++c) issue(c);
       }
-      const int slot = (g == 7) ? 15 : 8 + g;
-      const unsigned ring0 = (unsigned)(unsigned long long)ring + (unsigned)(sub * 16);
+      const bool nine = uni((int)ps.nine) != 0;
+      const bool helper = nine && g == 7;
+      const int slot = helper ? 8 + sub : ((g == 7) ? 15 : 8 + g); // (lane 63 of a 7-point stencil has fit == false)
+      const int pos = helper ? 8 : sub;                             // this lane's record of an iteration
+      const unsigned stride = nine ? 9u * 16u : 8u * 16u;
+      const unsigned ring0 = (unsigned)(unsigned long long)ring + (unsigned)(pos * 16);
       const unsigned slot_off = (unsigned)((slot >> 1) * 1024 + (slot & 1) * 8);
 #pragma unroll 1
       for (int c = 0; c < nchunk && any; ++c) {
@@ -1267,7 +1339,7 @@ struct ScatteredModel {
             double ln3, w2;
           };
           auto rd = [&](RecRegs &R, int i) {
-            const unsigned ra = cbase + (unsigned)(i * 128);
+            const unsigned ra = cbase + (unsigned)i * stride;
             asm volatile("ds_read_b128 %0, %5\n\t"
                          "ds_read_b128 %1, %5 offset:1024\n\t"
                          "ds_read_b128 %2, %5 offset:2048\n\t"
@@ -1280,31 +1352,36 @@ struct ScatteredModel {
           auto landed = [&](RecRegs &R) {
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(R.c0), "+v"(R.c1), "+v"(R.c2), "+v"(R.ln3), "+v"(R.w2) : : "memory");
           };
-          auto use = [&](const RecRegs &R, int i) {
-            const int k = c * 64 + 8 * i + sub;
-            const double w2 = k < n_list ? R.w2 : 0.0;
-            kept += w2 != 0.0 ? 1 : 0;
+          auto use = [&](const RecRegs &R) {
             const double ln[4] = {R.c1.y, R.c2.x, R.c2.y, R.ln3};
-            fold(w2, R.c0.x - p[0], R.c0.y - p[1], R.c1.x - p[2], ln);
+            fold(R.w2, R.c0.x - p[0], R.c0.y - p[1], R.c1.x - p[2], ln);
           };
           RecRegs Ra, Rb;
           rd(Ra, 0);
           landed(Ra);
 #pragma unroll 1
-          for (int i = 0; i < 8; i += 2) {
-            rd(Rb, i + 1);
-            use(Ra, i);
+          for (int i = 0; i < iters; i += 2) { // (iters = 8 or 7: wave-uniform)
+            rd(Rb, i + 1 < iters ? i + 1 : iters - 1);
+            use(Ra);
             landed(Rb);
-            rd(Ra, i + 2 < 8 ? i + 2 : 7); // (the last one is read for nothing)
-            use(Rb, i + 1);
+            rd(Ra, i + 2 < iters ? i + 2 : iters - 1); // (the last one is read for nothing)
+            if (i + 1 < iters) use(Rb);
             landed(Ra);
           }
         }
       }
       InterpModel::wait_vm<0>();
     }
-    kept_out = group_sum(kept);
     SRT_PHASE(4);
+    if (uni((int)ps.nine) != 0 && __any(fit)) { // the helpers' partial sums join their point's group (lane sub == 0 of it takes them)
+      SRT_LDS double *help = (SRT_LDS double *)const_cast<SRT_LDS int *>(list) + HELP_OFF;
+      __syncthreads(); // (block == one wave: the ring's reads are over)
+      if (g == 7 && sub < 7) each_sum([&](double &v, int t) { help[sub * NSUM + t] = v; });
+      __syncthreads();
+      if (g < 7 && sub == 0) each_sum([&](double &v, int t) { v += help[g * NSUM + t]; });
+      __syncthreads(); // (the area is reused below)
+      fit = fit && g < 7;
+    }
     // combine the 8 lanes' partial sums and solve
     fi.v[0] = fi.v[1] = fi.v[2] = fi.v[3] = 0.0;
     if (__any(fit)) {
@@ -1367,23 +1444,37 @@ struct ScatteredModel {
   // fit exists: its point has at least J samples (else status 2: too few samples, lsinterp_mod.f95:262-264)
   template <int J>
   __device__ __noinline__ bool sf_prepare(const double (&p)[3], bool live, unsigned long long livemask, int npts, int n_list,
-                                          SRT_LDS const int *list, double *rec, double dmax6, double d7, bool p7near) const {
+                                          SRT_LDS const int *list, double *rec, double dmax6, double d7, bool p7near,
+                                          int padded_len) const {
     sf_pass1(p, livemask, npts, n_list, list, rec, dmax6, d7, p7near);
-    sf_weights<J>(p, live, livemask, npts, n_list, list, rec, dmax6, d7, p7near, true);
+    sf_weights<J>(p, live, livemask, npts, n_list, list, rec, dmax6, d7, p7near, true, padded_len);
     return live && pass1_out(list)->cnt8[threadIdx.x >> 3] >= J;
   }
-  // `redo`: some point threw out too many samples (fewer than J kept: "use them all", lsinterp_mod.f95:319-323).  The list, the
-  // side arrays and pass 1's results are gone by then (the pair loop's ring and the parked totals have overwritten them), so
-  // the caller serves this stencil on the own-list path, which carries that rule itself (wave-uniform; rare).
+  // `redo`: some point threw out too many samples (fewer than J kept: "use them all", lsinterp_mod.f95:319-323), known once the
+  // weights are (kept8), i.e. before the pair loop: the caller serves this stencil on the own-list path, which carries that rule
+  // itself (wave-uniform; rare).  Also taken by a list whose padding would not fit the staging buffer.
   template <int J>
   __device__ __forceinline__ Fit4 shared_fit(const double (&p)[3], bool live, unsigned long long livemask, int npts, int n_list,
                                              SRT_LDS const int *list, double *rec, double dmax6, double d7, bool p7near,
                                              bool &redo) const {
-    const bool fit = sf_prepare<J>(p, live, livemask, npts, n_list, list, rec, dmax6, d7, p7near);
-    int kept = 0;
-    const Fit4 fi = sf_sums<J>(p, fit, n_list, list, rec, kept);
-    redo = __any(fit && kept < J);
-    return fi;
+    Fit4 fi;
+    fi.v[0] = fi.v[1] = fi.v[2] = fi.v[3] = 0.0;
+    const PairSplit ps(npts, n_list);
+    redo = ps.padded > REC_CAP;
+    if (redo) return fi;
+    bool fit = sf_prepare<J>(p, live, livemask, npts, n_list, list, rec, dmax6, d7, p7near, ps.padded);
+    const int g = threadIdx.x >> 3, sub = threadIdx.x & 7;
+    redo = __any(fit && pass1_out(list)->kept8[g] < J);
+    if (redo) return fi;
+    double ph[3] = {p[0], p[1], p[2]};
+    if (ps.nine) { // the helpers take their point's coordinates and its fit flag
+      const unsigned long long fitmask = __ballot(fit);
+      const int src = g == 7 ? 8 * sub : (int)threadIdx.x;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) ph[k] = __shfl(p[k], src);
+      if (g == 7) fit = sub < 7 && ((fitmask >> (8 * sub)) & 1ull) != 0ull;
+    }
+    return sf_sums<J>(ph, fit, n_list, list, rec, ps);
   }
   // The own-list path: the stencil straddles a grid cell, is too wide for the series, or the shared list would not
   // fit: every group scans the rows of its own point (8 lists of LIST_CAP, processed in pieces if they overflow) and

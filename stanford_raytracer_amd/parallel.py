@@ -51,26 +51,38 @@ def pack_rows_torch(rows, nrows, outputper):
     return packed.contiguous(), offsets
 
 
-_PACK_BUFFERS = {}  # (device, rows capacity, slot) -> worst-case packed buffer, reused from step to step
+_PACK_BUFFERS = {}  # (device, rows capacity, slot) -> worst-case packed buffer, reused from step to step (opt-in: slot=...)
 
 
-def pack_rows_device(rows, nrows, outputper, stream=None, slot=0):
+def release_pack_buffers(device=None):
+    """Drop the reused pack buffers (of one device, or all): 2.7 GB per slot at BASELINE config[2]."""
+    for k in [k for k in _PACK_BUFFERS if device is None or k[0] == device]:
+        del _PACK_BUFFERS[k]
+
+
+def pack_rows_device(rows, nrows, outputper, stream=None, slot=None):
     """srt_pack_rows_device on torch CUDA tensors -> (packed[n * slots, 20], offsets[n + 1]).  `packed` is a worst-case
-    buffer that is allocated once per (device, size, slot) and reused; its valid rows are the first offsets[n] -- a number
-    that stays ON THE DEVICE: nothing here waits for the GPU (the gather reads it together with the other ranks' counts).
-    `slot` separates the buffers of steps that are in flight together (trace_sharded_pipelined)."""
+    buffer; its valid rows are the first offsets[n] -- a number that stays ON THE DEVICE: nothing here waits for the GPU
+    (the gather reads it together with the other ranks' counts).
+    slot=None (default): a fresh buffer per call, the caller's to keep.  slot=k: ONE buffer per (device, size, k) that is
+    reused from call to call -- what a step loop wants (no allocation per step); a `packed` kept from an earlier call with
+    the same k is overwritten by the next.  Steps that are in flight together use different k (trace_sharded_pipelined);
+    release_pack_buffers() frees them."""
     import torch
 
     from . import api
 
     n, slots = rows.shape[0], rows.shape[1]
     cap = max(n * slots, 1)
-    key = (rows.device, cap, slot)
-    packed = _PACK_BUFFERS.get(key)
-    if packed is None:
-        for k in [k for k in _PACK_BUFFERS if k[0] == rows.device and k[2] == slot]:
-            del _PACK_BUFFERS[k]  # (a launch set of another size on this device: one buffer per slot is kept)
-        packed = _PACK_BUFFERS[key] = torch.empty((cap, ROW), dtype=torch.float64, device=rows.device)
+    if slot is None:
+        packed = torch.empty((cap, ROW), dtype=torch.float64, device=rows.device)
+    else:
+        key = (rows.device, cap, slot)
+        packed = _PACK_BUFFERS.get(key)
+        if packed is None:
+            for k in [k for k in _PACK_BUFFERS if k[0] == rows.device and k[2] == slot]:
+                del _PACK_BUFFERS[k]  # (a launch set of another size on this device: one buffer per slot is kept)
+            packed = _PACK_BUFFERS[key] = torch.empty((cap, ROW), dtype=torch.float64, device=rows.device)
     offsets = torch.empty(n + 1, dtype=torch.int64, device=rows.device)
     st = stream if stream is not None else torch.cuda.current_stream(rows.device)
     api._check(api.lib().srt_pack_rows_device(slots, outputper, n, rows.data_ptr(), nrows.data_ptr(), offsets.data_ptr(),

@@ -113,10 +113,15 @@ def test_pack_rows_edge_cases():
     assert off.cpu().tolist() == [0, 0, 1, 2, 4, 9, 14, 19]
     pt, offt = parallel.pack_rows_torch(rows, nrows, per)
     assert torch.equal(off, offt) and torch.equal(packed[:19], pt)
-    again, _ = parallel.pack_rows_device(rows, nrows, per)
-    assert again.data_ptr() == packed.data_ptr()  # one buffer per (device, size, slot), reused from step to step
+    fresh, _ = parallel.pack_rows_device(rows, nrows, per)
+    assert fresh.data_ptr() != packed.data_ptr()  # default: a buffer of the caller's own per call
+    first, _ = parallel.pack_rows_device(rows, nrows, per, slot=0)
+    again, _ = parallel.pack_rows_device(rows, nrows, per, slot=0)
+    assert again.data_ptr() == first.data_ptr()  # opt-in: one buffer per (device, size, slot), reused from step to step
     other, _ = parallel.pack_rows_device(rows, nrows, per, slot=1)
-    assert other.data_ptr() != packed.data_ptr() and torch.equal(other[:19], pt)
+    assert other.data_ptr() != first.data_ptr() and torch.equal(other[:19], pt)
+    parallel.release_pack_buffers()
+    assert not parallel._PACK_BUFFERS
     e = torch.zeros((0, slots, 20), dtype=torch.float64, device=dev)
     packed, off = parallel.pack_rows_device(e, torch.zeros(0, dtype=torch.int32, device=dev), per)
     assert off.cpu().tolist() == [0]

@@ -277,14 +277,90 @@ def test_full_size_config3_interp256_1m(interp256_model):
     m = interp256_model
     assert m.device_bytes == 257 ** 3 * 4 * 64 * 8
     pos, d, w = wl.launch_set(1_000_000, 3)
-    p = api.make_params(fixedstep=0, dt0=1e-3, dtmax=0.1, maxerr=5e-4, tmax=0.5, maxsteps=256, outputper=128, del_=1e-6,
-                        minalt=wl.MINALT)
+    # (the benchmarked configuration: bench.py WORKLOADS["interp256"] -- outputper 16, launch-cell order)
+    p = api.make_params(fixedstep=0, dt0=1e-3, dtmax=0.1, maxerr=5e-4, tmax=0.5, maxsteps=256, outputper=16, del_=1e-6,
+                        minalt=wl.MINALT, ray_order=1)
     rows, nrows, stop, steps = m.trace(pos, d, w, params=p)
     check_invariants(pos, rows, nrows, stop, steps, p)
     assert steps > 100_000_000
     idx = np.random.default_rng(6).choice(len(w), 8192, replace=False)
     r2, n2, s2, _ = m.trace(pos[idx], d[idx], w[idx], params=p)
     assert np.array_equal(r2, rows[idx]) and np.array_equal(n2, nrows[idx]) and np.array_equal(s2, stop[idx])
+
+
+@pytest.fixture(scope="module")
+def oracle256():
+    from oracle import oracle
+
+    F, b = wl.make_grid(256, half_width=10.0 * wl.R_E)
+    om = oracle.Model.interp(F, b, wl.QS, wl.MS)  # 8 arrays of 67 M doubles (4.3 GB), 15 s
+    del F
+    return om
+
+
+def points_256():
+    """Where the 256^3 table is probed: the launch region, the HIGHEST-index cells (cell number 256 of 0..256 on every axis:
+    the far end of 34.8 GB of addressing), all six clamped faces (a point below / above the grid on one axis, inside on
+    the others), edges and corners outside the grid on two / three axes, and exact node hits."""
+    rng = np.random.default_rng(256)
+    hw = 10.0 * wl.R_E
+    h = 2.0 * hw / 255.0
+    pts = [wl.launch_set(500, 256)[0]]
+    pts.append(rng.uniform(-hw, hw, (200, 3)))
+    pts.append(hw - h * rng.uniform(0.0, 1.0, (100, 3)))           # cell (254, 254, 254): the last interior cell
+    pts.append(hw - h * rng.uniform(0.0, 2.0, (60, 3)))
+    for ax in range(3):                                             # the six faces
+        for sign in (-1.0, 1.0):
+            q = rng.uniform(-hw, hw, (40, 3))
+            q[:, ax] = sign * (hw + rng.uniform(1.0, 3.0e6, 40))
+            pts.append(q)
+    q = rng.uniform(-hw, hw, (60, 3))                               # edges and corners
+    out = rng.integers(0, 2, (60, 3)).astype(bool)
+    out[:, 0] |= ~out.any(axis=1)
+    q[out] = (np.sign(q) * (hw + rng.uniform(1.0, 2.0e6, (60, 3))))[out]
+    pts.append(q)
+    nodes = (rng.integers(0, 256, (40, 3)) * ((2.0 * hw) / 255.0)) + (-hw)  # exact nodes (the adapter's own expression)
+    pts.append(nodes)
+    pts.append(np.array([[hw, hw, hw], [-hw, -hw, -hw], [hw, -hw, hw]]))
+    pts = np.concatenate(pts)
+    return pts[np.linalg.norm(pts, axis=1) > wl.R_E + 200e3]
+
+
+def test_value_parity_on_the_256_grid(interp256_model, oracle256):
+    """G0 and G2 by VALUE on the table the headline runs on (the oracle's 256^3 model is built from the same grid): densities
+    at >= 1000 points incl. the highest-index cells and the clamped faces, then gradients / the right-hand side where a
+    whistler-mode root exists.  Bars: those of the 16^3 tests (test_gpu_parity.py)."""
+    from oracle import oracle
+
+    g, o = interp256_model, oracle256
+    pts = points_256()
+    assert len(pts) >= 1000
+    gp = g.plasma_params(pts)
+    op = np.array([np.concatenate(o.plasma_params(p)) for p in pts])
+    rel = lambda a, b: np.abs(a - b) / np.maximum(np.abs(b), 1e-300)
+    assert rel(gp[:, 4:8], op[:, 4:8]).max() <= 1e-11
+    assert vrel(gp[:, 16:19], op[:, 16:19]).max() <= 2e-7
+    # the far corner cell really is the far end of the table
+    hw = 10.0 * wl.R_E
+    assert np.sum(np.all(pts > hw - 2.0 * hw / 255.0, axis=1) & np.all(pts < hw, axis=1)) >= 50
+    # G2: a wave normal on root 2 at every point that has one
+    rng = np.random.default_rng(257)
+    kd = rng.normal(size=pts.shape)
+    kd /= np.linalg.norm(kd, axis=1, keepdims=True)
+    w = 2.0 * np.pi * np.exp(rng.uniform(np.log(0.5e3), np.log(10e3), len(pts)))
+    kmag = np.array([o.disp(p, d, ww)[8] for p, d, ww in zip(pts, kd, w)])
+    ok = np.isfinite(kmag) & (kmag > 0)
+    assert ok.sum() >= 500
+    x, k, w = pts[ok], kd[ok] * kmag[ok, None], w[ok]
+    gg = g.gradients(x, k, w, 1e-6)
+    og = np.array([o.grad(a, b, c, 1e-6) for a, b, c in zip(x, k, w)])
+    assert vrel(gg[:, 0:3], og[:, 0:3]).max() <= 1e-7
+    assert rel(gg[:, 3], og[:, 3]).max() <= 1e-6
+    ex = vrel(gg[:, 4:7], og[:, 4:7])
+    assert np.median(ex) <= 1e-7 and np.percentile(ex, 95) <= 1e-5
+    assert vrel(gg[:, 7:10], og[:, 7:10]).max() <= 1e-6
+    ek = vrel(gg[:, 10:13], og[:, 10:13])
+    assert np.median(ek) <= 1e-6 and np.percentile(ek, 95) <= 2e-5
 
 
 def test_full_size_config4_interp_4m_shards(interp256_model):
@@ -295,8 +371,8 @@ def test_full_size_config4_interp_4m_shards(interp256_model):
 
     m = interp256_model
     pos, d, w = wl.launch_set(4_000_000, 4)
-    p = api.make_params(fixedstep=0, dt0=1e-3, dtmax=0.1, maxerr=5e-4, tmax=0.5, maxsteps=256, outputper=128, del_=1e-6,
-                        minalt=wl.MINALT, ray_order=1)
+    p = api.make_params(fixedstep=0, dt0=1e-3, dtmax=0.1, maxerr=5e-4, tmax=0.5, maxsteps=256, outputper=16, del_=1e-6,
+                        minalt=wl.MINALT, ray_order=1)  # (bench.py WORKLOADS["interp4m"]; 10.9 GB of rows)
     rows, nrows, stop, steps = m.trace(pos, d, w, params=p)
     check_invariants(pos, rows, nrows, stop, steps, p)
     assert steps > 500_000_000
@@ -317,8 +393,8 @@ def test_full_size_config5_scattered_1m(tmp_path):
     api.write_points_file(pf, np.concatenate([pts, lnN], axis=1), np.array([-10.0 * wl.R_E, 10.0 * wl.R_E] * 3), wl.QS, wl.MS, binary=True)
     m = api.Model.scattered_file(pf, window_scale=1.5, order=2, exact=0, local_window_scale=5.0)
     pos, d, w = wl.launch_set(1_000_000, 5)
-    p = api.make_params(fixedstep=0, dt0=1e-3, dtmax=0.1, maxerr=5e-4, tmax=0.5, maxsteps=64, outputper=32, del_=1e-6,
-                        minalt=wl.MINALT)
+    p = api.make_params(fixedstep=0, dt0=1e-3, dtmax=0.1, maxerr=5e-4, tmax=0.5, maxsteps=64, outputper=8, del_=1e-6,
+                        minalt=wl.MINALT)  # (bench.py WORKLOADS["scattered825k"])
     rows, nrows, stop, steps = m.trace(pos, d, w, params=p)
     check_invariants(pos, rows, nrows, stop, steps, p)
     assert steps > 50_000_000
