@@ -206,6 +206,11 @@ def build(force=False):
 # in this repository.  Flags follow the reference's Makefiles (fortran/Makefile:42-48, gcpm/Makefile, iri2007/Makefile:46-55,
 # xform/Makefile) minus gfortran-only options; further departures, each forced by flang:
 #   * raytracer_driver.f95:76 uses the GNU intrinsic iargc(): -cpp -Diargc=command_argument_count;
+#   * gcpm/*.for keep state in unSAVEd locals (ne_inner_ps_trough.for:156-171 caches x234 per date) and the reference's
+#     gfortran flags zero every local (-finit-local-zero, Makefile:10); flang has no such flag.  They are compiled with
+#     -fno-automatic = static, zero-initialised storage: the reference Makefile's own g95 variant (-fstatic, Makefile:6) and
+#     its commented gfortran line (Makefile:9).  Without it check_crossing (ne_inner_ps_trough.for:199-215) loops on garbage
+#     and STOPs;
 #   * AT64ThCh_adapter.f95 passes T04_s / IGRF_GSM as actual arguments without declaring them EXTERNAL: the
 #     declaration is streamed in by sed after its `implicit none` of funcPlasmaParams (never written to disk).
 DRIVER_MODULES = [
@@ -236,7 +241,7 @@ def build_driver(path_objs):
     jobs = []
     for f in GCPM_SOURCES:
         obj = os.path.join(OBJ, "gcpm_" + f[:-4] + ".o")
-        jobs.append((os.path.join(REF, "gcpm", f), obj, ["-ffixed-form", "-ffixed-line-length-132"], None))
+        jobs.append((os.path.join(REF, "gcpm", f), obj, ["-fno-automatic", "-ffixed-form", "-ffixed-line-length-132"], None))
         objs.append(obj)
     for f in IRI_SOURCES:
         obj = os.path.join(OBJ, "iri_" + f[:-4] + ".o")
@@ -257,6 +262,38 @@ def build_driver(path_objs):
     if not newer(exe, dobj, *objs):
         run([FC, *OPT, "-o", exe, dobj, *objs])
     print("build_ref: built", exe)
+    build_gridbuilders(objs)
+    return True
+
+
+# ---- the reference's own producers of model-3 / model-4 inputs ------------------------------------------------------------
+# fortran/gcpm_dens_model_buildgrid.f95 (regular grid, :190-329) and fortran/gcpm_dens_model_buildgrid_random.f95 (scattered
+# samples, :196-407) sample GCPM + IRI, which are out of scope for the HIP path: they are linked here only to PRODUCE the
+# real-data fixtures of tests/golden/make_gcpm_golden.py (plasmapause steps, ionospheric gradients, what the files hold
+# inside the Earth).  Same departures as the driver (iargc -> command_argument_count).  Both programs read the IRI/CCIR
+# coefficient files from the working directory: run them inside a scratch directory of symlinks to /root/reference/gcpm/*.
+GRIDBUILDER_MODULES = ["fortran/randomsampling_mod.f95", "fortran/gcpm_dens_model_buildgrid_random_helpermod.f95"]
+GRIDBUILDER_PROGRAMS = ["gcpm_dens_model_buildgrid", "gcpm_dens_model_buildgrid_random"]
+
+
+def build_gridbuilders(link_objs):
+    objs = list(link_objs)
+    for rel in GRIDBUILDER_MODULES:
+        src = os.path.join(REF, rel)
+        if not os.path.exists(src):
+            print("build_ref: %s missing -- grid builders not built" % rel)
+            return False
+        obj = os.path.join(OBJ, "gb_" + os.path.basename(rel)[:-4] + ".o")
+        compile_one(src, obj, [], None)
+        objs.append(obj)
+    for prog in GRIDBUILDER_PROGRAMS:
+        src = os.path.join(REF, "fortran", prog + ".f95")
+        pobj = os.path.join(OBJ, "gb_" + prog + ".o")
+        compile_one(src, pobj, ["-cpp", "-Diargc=command_argument_count"], None)
+        exe = os.path.join(OUT, prog)
+        if not newer(exe, pobj, *objs):
+            run([FC, *OPT, "-o", exe, pobj, *objs])
+        print("build_ref: built", exe)
     return True
 
 
