@@ -302,10 +302,12 @@ def run_workload(ctx, name, steps, warmup, rays_override=0, nstream=1, keep=Fals
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    last_gathered = [None]
+
     def one_step(i, cnt, tm):
         if gather:  # shard -> trace -> pack -> variable-length gather to rank 0: the tested multi-GPU path
             batch.out[0]["cnt"] = cnt
-            parallel.trace_sharded(dist, total, lambda a, b: batch.trace(0), pack, dst=0, timings=tm)
+            last_gathered[0] = parallel.trace_sharded(dist, total, lambda a, b: batch.trace(0), pack, dst=0, timings=tm)
         else:
             with torch.cuda.stream(streams[i % nstream]):
                 batch.launch(i % nstream, streams[i % nstream], counters=cnt)
@@ -355,17 +357,24 @@ def run_workload(ctx, name, steps, warmup, rays_override=0, nstream=1, keep=Fals
         "stop": o["stop"].cpu().numpy(), "nrows": o["nrows"].cpu().numpy(),
         "launch": (pos0[lo:hi], dir0[lo:hi], w0[lo:hi]), "field": fld,
     }
+    if gather and rank == 0 and last_gathered[0] is not None:
+        # what rank 0 holds after the last step's gather, as a number a one-GPU run of the same launch set must reproduce
+        pk, nr_all, st_all = last_gathered[0]
+        res["rows_checksum"] = rows_checksum(torch, pk, nr_all, st_all)
+        res["gathered_rows"] = int(pk.shape[0])
     if world == 1 and kind == "interp" and steps:
         # the fixed cost the multi-GPU step adds on every rank: packing the kept rows of this launch (srt_pack_rows_device)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         parallel.pack_rows_device(o["rows"], o["nrows"], p.outputper, slot=0)  # (allocates the reused buffer)
         torch.cuda.synchronize(dev)
         e0.record()
-        _, off = parallel.pack_rows_device(o["rows"], o["nrows"], p.outputper, slot=0)
+        pk, off = parallel.pack_rows_device(o["rows"], o["nrows"], p.outputper, slot=0)
         e1.record()
         torch.cuda.synchronize(dev)
         res["pack_ms_one_gpu"] = e0.elapsed_time(e1)
         res["packed_bytes_one_gpu"] = int(off[-1]) * 160
+        res["rows_checksum"] = rows_checksum(torch, pk[:int(off[-1])], o["nrows"], o["stop"])
+        res["gathered_rows"] = int(off[-1])
         parallel.release_pack_buffers(dev)
     if world == 1 and kind == "ngo" and steps and hi > lo:
         # what bounds this launch from below: its longest rays alone (<= 8 rays = one wave in tail mode, srt_models.hpp):
@@ -384,6 +393,21 @@ def run_workload(ctx, name, steps, warmup, rays_override=0, nstream=1, keep=Fals
     if keep:
         res["batch"] = batch
     return res
+
+
+def rows_checksum(torch, packed, nrows, stop):
+    """Position-weighted 64-bit sum (wrap-around) over the BITS of the packed kept rows [total, 20], the per-ray row counts and
+    stop codes, in ray order: equal for a one-GPU launch and for the gather of any number of shards iff every row of every ray
+    is bit-identical and in its place (rays are independent: raytracer_driver.f95:1144-1232 is a serial loop with no carried
+    state).  Computed where the tensors live."""
+    def wsum(t):
+        v = t.contiguous().view(torch.int64).reshape(-1) if t.dtype == torch.float64 else t.reshape(-1).to(torch.int64)
+        if v.numel() == 0:
+            return 0
+        wgt = torch.arange(v.numel(), dtype=torch.int64, device=v.device) % 1000003 + 1
+        return int((v * wgt).sum().item())
+    tot = (wsum(packed) * 3 + wsum(nrows) * 5 + wsum(stop) * 7) & 0xFFFFFFFFFFFFFFFF
+    return "%016x" % tot
 
 
 def pipelined_pass(ctx, name, rays_override=0, steps=3):
@@ -546,6 +570,10 @@ def main():
         else:
             other["interp4m"] = other_config_line(ctx, run_workload(ctx, "interp4m", 2, 1), None)
 
+    if want_other and world == 1 and os.environ.get("SRT_BENCH_CLI", "1") != "0":
+        progress("other config cli_end_to_end (the drop-in executable, files in, .ray text out)")
+        other["cli_end_to_end"] = cli_end_to_end(ctx, res)
+
     stream_gbs = None
     if rank == 0 and world == 1:
         # the box's own streaming rate ("measure a device-to-device copy and use THAT as 100 %"): read +
@@ -585,12 +613,16 @@ def main():
             "data": "synthetic",
             "config": {"workload": describe(res), "total_rays": res["total_rays"], "rays_per_gpu": res["rays_this_rank"],
                        "grid": res["grid"], "maxsteps": p.maxsteps, "outputper": p.outputper, "integrator": "rkf45 adaptive",
+                       "first_attempt_policy": int(p.first_attempt_policy),
                        "parallelism": "one launch set, contiguous shards x%d (parallel.trace_sharded)" % world if world > 1 else "1 GPU",
                        "ray_order": "launch-cell Morton order, sorted on the device inside the timed region" if (args.ray_order and kind == "interp") else "as given",
                        "gather": res["gather"], "streams": res["nstream"]},
             "roofline": roofline_of(res, k_ms, steps_rank0, traffic, traffic_note, stream_gbs, khash),
             "detail": detail_of(res),
         }
+        if "rows_checksum" in res:
+            out["detail"]["rows_checksum"] = res["rows_checksum"]
+            out["detail"]["packed_rows"] = res["gathered_rows"]
         if world == 1 and "pack_ms_one_gpu" in res:
             out["multi_gpu_parts"] = {"pack_ms": res["pack_ms_one_gpu"], "packed_bytes": res["packed_bytes_one_gpu"],
                                       "note": "the fixed per-rank cost of a multi-GPU step measured here on one GPU: packing the kept rows "
@@ -622,6 +654,79 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def cli_end_to_end(ctx, res):
+    """The product's own user-visible path for the headline config: `bin/raytracer` (the reference driver's flags) from a TEXT
+    ray file + a binary grid file to a `.ray` TEXT file in the reference's record format (raytracer_driver.f95:1146,
+    :1197-1217), all files in /dev/shm, phases from the executable's own --timing=1 line.  Run once per value of
+    --first_attempt_policy: 1 is the executable's default (the reference's gfortran behaviour), 0 is what the API, the goldens
+    and this bench's headline use (raytracer.f95:778-788)."""
+    import subprocess
+
+    from stanford_raytracer_amd import api, workloads as wl
+
+    if res["kind"] != "interp":
+        return {"skipped": "headline workload is not the interp model"}
+    exe = os.path.join(ROOT, "stanford_raytracer_amd", "bin", "raytracer")
+    if not os.path.exists(exe):
+        return {"skipped": "stanford_raytracer_amd/bin/raytracer is not built"}
+    p = res["params"]
+    n = res["total_rays"]
+    slots = (p.maxsteps - 1) // p.outputper + 2
+    need = n * slots * 830 + res["grid"] ** 3 * 32 + n * 200          # worst-case .ray text + grid + ray file
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else ctx.tmp
+    try:
+        free = shutil.disk_usage(base).free
+    except OSError:
+        free = 0
+    if free < need * 1.1:
+        return {"skipped": "%s has %.1f GB free, the files need up to %.1f GB" % (base, free / 1e9, need / 1e9)}
+    td = tempfile.mkdtemp(prefix="srt_cli_", dir=base)
+    out = {"files_in": base}
+    try:
+        t0 = time.time()
+        F, b = wl.make_grid(res["grid"], half_width=10.0 * wl.R_E)
+        gf = os.path.join(td, "grid.bin")
+        api.write_grid_file(gf, F, b, wl.QS, wl.MS, binary=True)
+        del F
+        pos0, dir0, w0 = wl.launch_set(n, WORKLOADS[res["workload"]]["seed"])
+        rf = os.path.join(td, "rays.txt")
+        np.savetxt(rf, np.concatenate([pos0, dir0, w0[:, None]], axis=1), fmt="%.17g")
+        out["inputs"] = {"grid_file_GB": os.path.getsize(gf) / 1e9, "grid_format": "SRTGRID1 (binary side-format; text grids are accepted too)",
+                         "rays_file_GB": os.path.getsize(rf) / 1e9, "write_s": time.time() - t0}
+        ofile = os.path.join(td, "out.ray")
+        cmd = [exe, "--outputper=%d" % p.outputper, "--dt0=%r" % p.dt0, "--dtmax=%r" % p.dtmax, "--tmax=%r" % p.tmax, "--root=%d" % p.root,
+               "--fixedstep=0", "--maxerr=%r" % p.maxerr, "--maxsteps=%d" % p.maxsteps, "--minalt=%r" % p.minalt,
+               "--inputraysfile=%s" % rf, "--outputfile=%s" % ofile, "--modelnum=3", "--interp_interpfile=%s" % gf,
+               "--yearday=2010001", "--milliseconds_day=0", "--use_tsyganenko=0", "--use_igrf=0", "--ray_order=%d" % p.ray_order,
+               "--timing=1"]
+        for pol in (1, 0):
+            t0 = time.time()
+            r = subprocess.run(cmd + ["--first_attempt_policy=%d" % pol], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+            wall = time.time() - t0
+            key = "first_attempt_policy_%d" % pol
+            if r.returncode != 0:
+                out[key] = {"error": "rc %d: %s" % (r.returncode, r.stderr.strip()[-300:])}
+                continue
+            tline = [ln for ln in r.stdout.splitlines() if ln.startswith(" timing: ")]
+            sline = [ln for ln in r.stdout.splitlines() if "accepted steps" in ln]
+            ph = json.loads(tline[-1][len(" timing: "):]) if tline else {}
+            acc = int(sline[-1].split()[2]) if sline else None
+            gb = os.path.getsize(ofile) / 1e9
+            out[key] = {"process_wall_s": wall, "phases_s": {k: ph.get(k) for k in ("parse_s", "model_s", "trace_s", "write_s", "wall_s")},
+                        "accepted_steps": acc, "ray_file_GB": gb, "records": int(os.path.getsize(ofile) // 823),
+                        "writer_GBs": (gb / ph["write_s"]) if ph.get("write_s") else None,
+                        "rays_per_s_end_to_end": n / wall, "accepted_steps_per_s_end_to_end": (acc / wall) if acc else None}
+            os.remove(ofile)
+        out["note"] = ("%d rays through bin/raytracer, one device; trace_s holds the host<->device copies of srt_trace_batch (PCIe-inclusive) "
+                       "and the chunks' kernels, write_s the text formatting on all host cores, overlapped with the next chunk's trace; "
+                       "policy 1 = the executable's default, policy 0 = the headline's" % n)
+    except Exception as e:  # pragma: no cover
+        out["error"] = "%s: %s" % (type(e).__name__, e)
+    finally:
+        shutil.rmtree(td, ignore_errors=True)
+    return out
 
 
 def roofline_of(res, k_ms, steps_per_launch, traffic, traffic_note, stream_gbs, khash):

@@ -60,8 +60,13 @@ typedef struct srt_params {
   int32_t root;      /* 1 or 2 (2 = whistler) */
   int32_t fixedstep; /* 1 = RK4, 0 = adaptive RKF45 */
   int32_t outputper; /* keep rows 0, outputper, 2*outputper, ... (driver:1197) */
-  int32_t first_attempt_policy; /* 0: NaN error term => accept, no growth (flang; SURVEY A-1)
-                                   1: error from the k term alone (gfortran<=8) */
+  int32_t first_attempt_policy; /* a ray's FIRST adaptive attempt, where raytracer.f95:778 reads an unset local (SURVEY A-1):
+                                   0: NaN error term => accepted at dt0, dt not grown (what a flang build of the reference does,
+                                      hence the goldens of this repository, api.make_params and bench.py);
+                                   1: error from the k term alone (what the reference's own gfortran toolchain does; the
+                                      `raytracer` executable's default, --first_attempt_policy).
+                                   THE LIBRARY HAS NO DEFAULT: this member is read as given (a zeroed struct = 0); callers
+                                   that replace a gfortran-built reference set 1.  INTEGRATION.md section 3. */
   int32_t refill_threshold;     /* free lanes per wave before new rays are claimed (0 = default) */
   int32_t ray_order;            /* order in which the launch set is WORKED ON (results and their order are unchanged):
                                    0 = as given; 1 = sorted on the device by the Morton code of the launch cell, so

@@ -5,6 +5,7 @@
 // text between column 3 and the first '=' equals the name wins; unknown flags are ignored.  Numeric integer
 // flags are read as reals and floored (driver:195-196).  Where the reference leaves an unset flag
 // uninitialised we fail with a message instead (documented divergence).
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -63,6 +64,10 @@ static void need(bool ok, const char *name) {
       return 1;                                                          \
     }                                                                    \
   } while (0)
+
+static double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 // model flags of the driver (raytracer_driver.f95:256-770) -> model handle; del = the driver's FD step for the model
 static int make_model(int device, srt_model **out, double *del) {
@@ -132,12 +137,14 @@ int main(int argc, char **argv) {
          "  model 3: --interp_interpfile --yearday --milliseconds_day --use_tsyganenko=0|1 --use_igrf=0|1\n"
          "  model 4: model 3 flags + --scattered_interp_window_scale --scattered_interp_order\n"
          "           --scattered_interp_exact --scattered_interp_local_window_scale\n"
-         "  extra:   --device=N | --devices=0,1,..  --chunk_rays=N  --ray_order=0|1\n"
+         "  extra:   --device=N | --devices=0,1,..  --chunk_rays=N  --ray_order=0|1  --timing=1 (wall clock per phase)\n"
          "           --first_attempt_policy=1|0: error estimate of a ray's first adaptive attempt, where the reference reads an\n"
          "             unset variable: 1 (default) = from the k term alone, as the reference's gfortran build behaves;\n"
          "             0 = NaN => accepted at dt0, dt not grown, as a flang build behaves (the goldens of this repository)\n"
          "  tools:   --grid2bin_in=<text grid> --grid2bin_out=<binary grid>   (convert and exit; --interp_interpfile\n"
          "           accepts either form);  --pts2bin_in / --pts2bin_out: the same for model-4 sample files\n"
+         "           --buildgrid=1 --filename=<out> --minx .. --maxz --nx --ny --nz --compder=0|1 (the reference's regular grid\n"
+         "           builder gcpm_dens_model_buildgrid with the model of --modelnum in place of GCPM; --binary=1)\n"
          "           --buildsamples=1 --filename=<out> --minx .. --maxz --n_initial_uniform ... (the reference's random grid\n"
          "           builder with the model of --modelnum in place of GCPM; --seed, --binary=1)\n"
          "           --damping_out=<file>: hot-plasma damping along the kept rows (raynum, row, t, rate, magnitude, flag);\n"
@@ -157,6 +164,46 @@ int main(int argc, char **argv) {
     if (getopt_named("pts2bin_in", pin)) {
       need(getopt_named("pts2bin_out", pout), "pts2bin_out");
       CHECK(srt_points_file_convert(pin.c_str(), pout.c_str()));
+      return 0;
+    }
+  }
+  {
+    // the reference's gcpm_dens_model_buildgrid with the model of --modelnum in place of GCPM: same flags
+    // (gcpm_dens_model_buildgrid.f95:42-160: --minx .. --maxz, --nx --ny --nz (reals, floored), --compder, --filename) and
+    // the builder's exact text layout (:302-327, srt_grid_file_write); ours: --binary=1 (SRTGRID1), --device
+    std::string flag;
+    if (getopt_named("buildgrid", flag) && flag != "0") {
+      std::string out;
+      need(getopt_named("filename", out), "filename");
+      double b[6], v = 0;
+      const char *bn[6] = {"minx", "maxx", "miny", "maxy", "minz", "maxz"};
+      for (int k = 0; k < 6; ++k) need(get_real(bn[k], b[k]), bn[k]);
+      int n3[3] = {0, 0, 0}, compder = 0, device = 0, binary = 0;
+      const char *nn[3] = {"nx", "ny", "nz"};
+      for (int k = 0; k < 3; ++k) {
+        need(get_real(nn[k], v), nn[k]);
+        n3[k] = (int)floor(v);
+        if (n3[k] < 2) {
+          fprintf(stderr, "raytracer: --%s must be >= 2 (the interpolated model needs two nodes per axis)\n", nn[k]);
+          return 2;
+        }
+      }
+      if (get_real("compder", v)) compder = (int)floor(v);
+      get_int("device", device);
+      get_int("binary", binary);
+      srt_model *m = nullptr;
+      double del = 0.0;
+      int rc = make_model(device, &m, &del);
+      if (rc) return rc;
+      const int nspec = srt_model_nspec(m);
+      const size_t nval = (size_t)n3[0] * n3[1] * n3[2] * nspec;
+      std::vector<double> F(nval), D(compder ? 7 * nval : 0);
+      CHECK(srt_build_grid(m, compder ? 1 : 0, n3[0], n3[1], n3[2], b, F.data(), compder ? D.data() : nullptr));
+      double qs[SRT_MAXSPEC], ms[SRT_MAXSPEC];
+      srt_model_species(m, qs, ms);
+      CHECK(srt_grid_file_write(out.c_str(), binary, nspec, n3[0], n3[1], n3[2], b, qs, ms, F.data(), compder ? D.data() : nullptr));
+      printf(" %d x %d x %d nodes, %d species%s\n", n3[0], n3[1], n3[2], nspec, compder ? ", 7 derivative blocks" : "");
+      srt_model_destroy(m);
       return 0;
     }
   }
@@ -309,8 +356,12 @@ int main(int argc, char **argv) {
     if (devices.empty()) devices.push_back(device);
   }
   const int ndev = (int)devices.size();
+  int timing = 0;
+  get_int("timing", timing);
+  const double t_start = now_s();
   double *pos0 = nullptr, *dir0 = nullptr, *w0 = nullptr;
   int64_t nrays = srt_read_rays_file(rays_path.c_str(), &pos0, &dir0, &w0);
+  const double parse_s = now_s() - t_start;
   if (nrays < 0) {
     fprintf(stderr, "raytracer: %s\n", srt_last_error());
     return 1;
@@ -342,6 +393,8 @@ int main(int argc, char **argv) {
     int64_t lo = 0, hi = 0, steps = 0;
     std::string out, damp;
     int rc = 0;
+    double model_s = 0, trace_s = 0, write_s = 0; // --timing=1: wall clock of the phases (write_s runs beside the next trace)
+    int64_t out_bytes = 0;
   };
   std::vector<Shard> shards(ndev);
   const int64_t per_dev = (nrays + ndev - 1) / ndev;
@@ -356,8 +409,10 @@ int main(int argc, char **argv) {
   auto run_shard = [&](Shard &sh) -> int {
     srt_model *m = nullptr;
     double del = 0.0;
+    const double tm0 = now_s();
     int rc = make_model(sh.device, &m, &del);
     if (rc) return rc;
+    sh.model_s = now_s() - tm0;
     srt_params q = p;
     q.del = del;
     const int slots = srt_rows_per_ray(&q);
@@ -395,7 +450,9 @@ int main(int argc, char **argv) {
       c->nrows.resize(n);
       c->stop.resize(n);
       int64_t steps = 0;
+      const double tt0 = now_s();
       CHECK(srt_trace_batch(m, &q, n, pos0 + 3 * lo, dir0 + 3 * lo, w0 + lo, c->rows.data(), c->nrows.data(), c->stop.data(), &steps));
+      sh.trace_s += now_s() - tt0;
       sh.steps += steps;
       const bool damp = !sh.damp.empty();
       if (damp) {
@@ -408,7 +465,9 @@ int main(int argc, char **argv) {
       if (int rc = finish()) return rc;
       const bool first = lo == sh.lo;
       pending = std::async(std::launch::async, [=, &sh, &q]() -> int {
+        const double tw0 = now_s();
         if (srt_write_ray_file(sh.out.c_str(), 1, lo + 1, n, &q, nspec, qs, ms, w0 + lo, c->rows.data(), c->nrows.data(), c->stop.data())) return 1;
+        sh.write_s += now_s() - tw0;
         if (damp) {
           FILE *f = fopen(sh.damp.c_str(), first ? "w" : "a");
           if (!f) return 1;
@@ -467,6 +526,24 @@ int main(int argc, char **argv) {
     }
   }
   printf(" %lld rays, %lld accepted steps\n", (long long)nrays, (long long)total_steps);
+  if (timing) {
+    // ours (--timing=1): wall clock per phase, max over the shards (they run side by side); the writer of chunk k runs beside
+    // the trace of chunk k + 1, so trace_s + write_s may exceed wall_s
+    double model_s = 0, trace_s = 0, write_s = 0;
+    for (auto &sh : shards) {
+      model_s = std::max(model_s, sh.model_s);
+      trace_s = std::max(trace_s, sh.trace_s);
+      write_s = std::max(write_s, sh.write_s);
+    }
+    long long bytes = 0;
+    if (FILE *f = fopen(out_path.c_str(), "rb")) {
+      if (fseeko(f, 0, SEEK_END) == 0) bytes = (long long)ftello(f);
+      fclose(f);
+    }
+    printf(" timing: {\"parse_s\": %.3f, \"model_s\": %.3f, \"trace_s\": %.3f, \"write_s\": %.3f, \"wall_s\": %.3f, \"out_bytes\": %lld, "
+           "\"first_attempt_policy\": %d, \"devices\": %d}\n", parse_s, model_s, trace_s, write_s, now_s() - t_start, bytes,
+           (int)p.first_attempt_policy, ndev);
+  }
   srt_free(pos0);
   srt_free(dir0);
   srt_free(w0);

@@ -554,6 +554,16 @@ struct ScatteredModel {
   static constexpr int LDS_SCRATCH_SLOT = LIST_DOUBLES, LDS_BLOCK_SLOT = LDS_SCRATCH_SLOT + 1, LDS_PARK = LDS_SCRATCH_SLOT + 2,
                        LDS_PHASE = LDS_PARK + 32, LDS_HDR = LDS_SCRATCH_SLOT + 64;
   static constexpr int LDS_DOUBLES = LDS_HDR + 4 * 64;
+#ifndef SRT_SCAT_FUSED
+// 1: the weights and the pair loop of the shared path run FUSED, tile by tile (sf_fused): the 64 records of a tile --
+// {x, y, z, ln N_s, the eight half-weights} -- exist only in LDS, between the lanes that weigh them (lane = sample) and the
+// groups that sum them (lane = (point, 1 of 8)).  Nothing of a record goes to device memory any more except {r_c, cos, sin} of
+// the samples beyond the LDS side arrays; the sample itself is gathered twice (pass 1, fused pass) from the sample array.
+// 0 (default until measured faster): the three-phase form with the staging records written twice and read back through the LDS-DMA ring.
+#define SRT_SCAT_FUSED 0
+#endif
+  static constexpr bool FUSED = SRT_SCAT_FUSED != 0;
+  static constexpr int TILE_BYTES = 8192; // 64 records x 128 B, [16-byte chunk][record], at the END of the list area
   // candidate block of a lane: BLOCK_CAP entries {float dx, dy, dz (from the block's centre), int sample index}
   static constexpr int BLOCK_CAP = 4096, BLOCK_DOUBLES = 64 * BLOCK_CAP * 2;
   static constexpr int TRIP_MAX = 9 * 64; // entries one trip of a 27-cell scan can add
@@ -677,8 +687,12 @@ struct ScatteredModel {
 #pragma unroll
       for (int l = 0; l < j; ++l) s -= at(l, j) * at(l, j);
       if (!(s > 0.0)) return 1;
+#ifdef SRT_SCAT_RSQ
       double ujj, inv; // (a positive pivot of sums of squares of O(1) offsets: normal range)
       fm::sqrt_and_inv_pos(s, ujj, inv);
+#else
+      const double ujj = fm::sqrt_pos(s), inv = fdiv(1.0, ujj); // (a positive pivot of sums of squares of O(1) offsets: normal range)
+#endif
       at(j, j) = ujj;
       rinv[j] = inv;
 #pragma unroll
@@ -811,7 +825,6 @@ struct ScatteredModel {
   struct Pass1Out {
     double hin8[8];
     int cnt8[8];
-    int kept8[8]; // written by sf_weights: samples of the point's window that stay above the weight mask (:316-317)
   };
   __device__ __forceinline__ static SRT_LDS Pass1Out *pass1_out(SRT_LDS const int *list) {
     return (SRT_LDS Pass1Out *)((SRT_LDS double *)const_cast<SRT_LDS int *>(list) + LDS_PARK);
@@ -833,6 +846,26 @@ struct ScatteredModel {
     S.b = S.a + S.cap;
     S.c = S.b + S.cap;
     return S;
+  }
+  // The fused form: the list area is [list | {cos, sin} of cap samples | r_c of cap samples | .. | tile]; x, y, z come with the
+  // sample's second gather.  A shared list must leave the tile its 8 KiB: FUSED_LIST_CAP entries at most.
+  struct Side2 {
+    SRT_LDS d2_t *cs;
+    SRT_LDS double *rc;
+    int cap;
+  };
+  static constexpr int FUSED_LIST_CAP = (LIST_DOUBLES * 8 - TILE_BYTES) / 4 - 64;
+  __device__ __forceinline__ static Side2 side2_of(SRT_LDS const int *list, int n_list) {
+    const int used = (n_list + 3) >> 2; // 16-byte units the list occupies
+    Side2 S;
+    const int room = LIST_DOUBLES * 8 - TILE_BYTES - used * 16;
+    S.cap = room > 0 ? room / 24 : 0;
+    S.cs = (SRT_LDS d2_t *)const_cast<SRT_LDS int *>(list) + used;
+    S.rc = (SRT_LDS double *)(S.cs + S.cap);
+    return S;
+  }
+  __device__ __forceinline__ static SRT_LDS char *tile_of(SRT_LDS const int *list) {
+    return (SRT_LDS char *)const_cast<SRT_LDS int *>(list) + (LIST_DOUBLES * 8 - TILE_BYTES);
   }
   // p7near: the free point 7 lies as close to the centre as the six offset points may (<= 1e-3 radius) and takes the
   // addition theorem / the series like them; else its window is evaluated by cos() and its weight by etainv().
@@ -862,6 +895,7 @@ struct ScatteredModel {
 #pragma unroll
     for (int gg = 0; gg < 8; ++gg) lv8[gg] = (livemask >> (8 * gg)) & 1ull; // wave-uniform
     const Side side = side_of(list, n_list);
+    const Side2 side2 = side2_of(list, n_list);
     // the points' offsets from the centre (as in sf_weights)
     const double reps = radius * 5.0e-16;
     const double da3[3] = {pg[1][0] - pg[0][0], pg[3][1] - pg[0][1], pg[5][2] - pg[0][2]};
@@ -966,6 +1000,16 @@ struct ScatteredModel {
           c8[7] += 1;
         }
       }
+      if constexpr (FUSED) {
+        if (k < side2.cap) {
+          side2.cs[k] = d2_t{ca, sa};
+          side2.rc[k] = rc;
+        } else { // a list longer than the side arrays: through the staging buffer
+          *chunk(rec, 4, k) = d2_t{rc, 0.0};
+          *chunk(rec, 5, k) = d2_t{ca, sa};
+        }
+        continue;
+      }
       *chunk(rec, 0, k) = qa;
       *chunk(rec, 1, k) = qb;
       *chunk(rec, 2, k) = qc;
@@ -1012,11 +1056,10 @@ struct ScatteredModel {
   }
 
   // All eight half-weights of every sample of the list (see above); usemask: the reference's weight > 1e-16 mask (:316-317)
-  // padded_len: records [n_list, padded_len) get zero weights (the pair loop reads whole chunks and tests no index)
   template <int J>
   __device__ __forceinline__ void sf_weights(const double (&p_in)[3], bool live, unsigned long long livemask, int npts, int n_list,
                                           SRT_LDS const int *list, double *rec_flat, double dmax6, double d7, bool p7near,
-                                          bool usemask, int padded_len) const {
+                                          bool usemask) const {
     const ScatteredModel M = uniform_copy();
     const double p[3] = {p_in[0], p_in[1], p_in[2]};
     const double radius = M.radius;
@@ -1024,10 +1067,9 @@ struct ScatteredModel {
     const int lane = threadIdx.x, g = lane >> 3;
     const double r2 = radius * radius, pi_R = PI / radius, reps = radius * 5.0e-16;
     SRT_PHASE_BEGIN(list);
-    SRT_LDS Pass1Out *o = pass1_out(list);
+    SRT_LDS const Pass1Out *o = pass1_out(list);
     double hin8[8], pg[8][3];
     bool fit8[8], lv8[8];
-    int kept_c[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // wave-uniform: samples that keep a non-zero weight at point g
 #pragma unroll
     for (int gg = 0; gg < 8; ++gg) {
       hin8[gg] = uni(o->hin8[gg]);
@@ -1157,10 +1199,6 @@ struct ScatteredModel {
       *chunk(rec, 5, k) = d2_t{w8[2], w8[3]};
       *chunk(rec, 6, k) = d2_t{w8[4], w8[5]};
       *chunk(rec, 7, k) = d2_t{w8[6], w8[7]};
-      // (one compare per point and sample here instead of a compare + add per (point, neighbour) in the pair loop; the count
-      // itself is scalar arithmetic)
-#pragma unroll
-      for (int gg = 0; gg < 8; ++gg) kept_c[gg] += __popcll(__ballot(w8[gg] != 0.0));
     };
     // the samples whose {x, y, z, r_c, cos, sin} wait in LDS: no load from device memory in this loop, so nothing in it ever
     // waits for the previous trip's stores
@@ -1173,45 +1211,14 @@ struct ScatteredModel {
       const d2_t c0 = *chunk(rec, 0, k), c1 = *chunk(rec, 1, k), c4 = *chunk(rec, 4, k), c5 = *chunk(rec, 5, k);
       weigh(k, c0, d2_t{c1.x, c4.x}, c5);
     }
-#pragma unroll 1
-    for (int k = n_list + lane; k < padded_len; k += 64) {
-      const d2_t z = {0.0, 0.0};
-      *chunk(rec, 4, k) = z;
-      *chunk(rec, 5, k) = z;
-      *chunk(rec, 6, k) = z;
-      *chunk(rec, 7, k) = z;
-    }
-    if (lane == 0) {
-#pragma unroll
-      for (int gg = 0; gg < 8; ++gg) o->kept8[gg] = kept_c[gg];
-    }
     __syncthreads(); // block == one wave: the weights written above are read by other lanes next
     SRT_PHASE(3);
   }
 
-  // The pair loop's split of a stencil's records over the lanes.  8 points (the end-point stencil): group g = point g, its 8
-  // lanes take records 8 i + sub of a 64-record chunk.  7 points (every evalrhs stencil): group 7 has no point, so its lane h
-  // HELPS point h -- 9 lanes per point, records 9 i + (sub | 8 for the helper) of a 63-record chunk, 7 iterations per chunk
-  // instead of 8 -- and hands its partial sums to group h through LDS before the group reductions (lane 63 idles).
-  struct PairSplit {
-    bool nine;
-    int per, iters, nchunk, padded;
-    __device__ __forceinline__ PairSplit(int npts, int n_list) {
-#ifndef SRT_SCAT_NINE
-#define SRT_SCAT_NINE 1 // (0: the 8-way split for every stencil, for A/B)
-#endif
-      nine = SRT_SCAT_NINE != 0 && npts == 7;
-      per = nine ? 63 : 64;
-      iters = nine ? 7 : 8;
-      nchunk = (n_list + per - 1) / per;
-      padded = nchunk * per + (64 - per); // (the DMA of a chunk moves 64 records)
-    }
-  };
-  // Normal equations of this group's point from the finished records, and the solve.  p_in / fit: of the point this lane sums
-  // for (a helper lane's: its point's, see PairSplit).
+  // Normal equations of this group's point from the finished records, and the solve
   template <int J>
   __device__ __noinline__ Fit4 sf_sums(const double (&p_in)[3], bool fit, int n_list, SRT_LDS const int *list, double *rec_flat,
-                                       const PairSplit ps) const {
+                                       int &kept_out) const {
     Fit4 fi;
     const double p[3] = {p_in[0], p_in[1], p_in[2]}; // in registers: the asm statements below clobber memory
     SRT_AS1 double *const rec = (SRT_AS1 double *)rec_flat;
@@ -1222,6 +1229,7 @@ struct ScatteredModel {
     double A[(O3 || J == 10) ? 1 : NT], b[O3 ? 1 : J][4];
     double Mm[J == 10 ? Moments::N : 1]; // order 2: the 35 moments stand in for the 55 entries of A while summing
     typename std::conditional<O3, Sums20, int>::type S20;
+    int kept = 0;
     if constexpr (O3) S20.zero();
 #pragma unroll
     for (int t = 0; t < ((O3 || J == 10) ? 1 : NT); ++t) A[t] = 0.0;
@@ -1265,62 +1273,28 @@ struct ScatteredModel {
         }
       }
     };
-    // every running sum of this lane, in one fixed order (the helpers' hand-over below)
-    auto each_sum = [&](auto f) {
-      if constexpr (O3) {
-#pragma unroll
-        for (int t = 0; t < MomentsT<3>::N; ++t) f(S20.Mm[t], t);
-#pragma unroll
-        for (int a = 0; a < 20; ++a)
-#pragma unroll
-          for (int s = 0; s < 4; ++s) f(S20.b[a][s], MomentsT<3>::N + 4 * a + s);
-      } else {
-        constexpr int NA = J == 10 ? Moments::N : NT;
-        if constexpr (J == 10) {
-#pragma unroll
-          for (int t = 0; t < NA; ++t) f(Mm[t], t);
-        } else {
-#pragma unroll
-          for (int t = 0; t < NA; ++t) f(A[t], t);
-        }
-#pragma unroll
-        for (int a = 0; a < J; ++a)
-#pragma unroll
-          for (int s = 0; s < 4; ++s) f(b[a][s], NA + 4 * a + s);
-      }
-    };
-    constexpr int NSUM = O3 ? MomentsT<3>::N + 80 : (J == 10 ? Moments::N : NT) + 4 * J;
-    constexpr int HELP_OFF = 700; // doubles into the list area: behind the parked totals of order 2 (8 x 80)
-    static_assert(HELP_OFF + 7 * NSUM <= LIST_DOUBLES && HELP_OFF >= 8 * 80, "the helpers' hand-over must fit the list area");
     // The records come back through a ring of NBUF 64-record buffers in LDS (the list area: the list is dead by now),
     // filled by LDS-DMA NBUF - 1 buffers ahead -- the staging buffers of the CU's waves do not stay in L2 (the scans of
     // the other waves stream through it).
     // Buffer layout: [16-byte chunk t of the record][record] -- DMA instruction t moves chunk t of 64 records (lane =
-    // record), and the lanes of a group read neighbouring 16-byte slots (all groups the same ones: broadcast).
-    // No index test and no count in the loop: the records behind the list carry zero weights (sf_weights; their x, y, z,
-    // ln N are the last record's: finite), and what survives the weight mask was counted there.
+    // record), and the 8 lanes of a group read 8 neighbouring 16-byte slots (all 8 groups the same ones: broadcast).
     {
-      // (wave-uniform, but arguments of an out-of-line function arrive in vector registers: back to scalars)
-      const int nchunk = uni(ps.nchunk), per = uni(ps.per), iters = uni(ps.iters);
+      const int nchunk = (n_list + 63) >> 6; // wave-uniform
       SRT_AS3 char *const ring = (SRT_AS3 char *)list;
       auto issue = [&](int c) {
-        const int r = c * per + lane;
-        const int rc = r < n_list ? r : n_list - 1;
+        int r = c * 64 + lane;
+        r = r < n_list ? r : n_list - 1;
         SRT_AS3 char *dst = ring + (c % NBUF) * 8192;
 #pragma unroll
         for (int t = 0; t < 8; ++t) // (chunk-major staging: instruction t reads 1 KiB of consecutive bytes)
-          __builtin_amdgcn_global_load_lds((const SRT_AS1 void *)chunk(rec, t, t < 4 ? rc : r), (SRT_AS3 void *)(dst + 1024 * t), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((const SRT_AS1 void *)chunk(rec, t, r), (SRT_AS3 void *)(dst + 1024 * t), 16, 0, 0);
       };
       const bool any = __any(fit);
       if (any) {
         for (int c = 0; c < NBUF - 1 && c < nchunk; ++c) issue(c);
       }
-      const bool nine = uni((int)ps.nine) != 0;
-      const bool helper = nine && g == 7;
-      const int slot = helper ? 8 + sub : ((g == 7) ? 15 : 8 + g); // (lane 63 of a 7-point stencil has fit == false)
-      const int pos = helper ? 8 : sub;                             // this lane's record of an iteration
-      const unsigned stride = nine ? 9u * 16u : 8u * 16u;
-      const unsigned ring0 = (unsigned)(unsigned long long)ring + (unsigned)(pos * 16);
+      const int slot = (g == 7) ? 15 : 8 + g;
+      const unsigned ring0 = (unsigned)(unsigned long long)ring + (unsigned)(sub * 16);
       const unsigned slot_off = (unsigned)((slot >> 1) * 1024 + (slot & 1) * 8);
 #pragma unroll 1
       for (int c = 0; c < nchunk && any; ++c) {
@@ -1339,7 +1313,7 @@ struct ScatteredModel {
             double ln3, w2;
           };
           auto rd = [&](RecRegs &R, int i) {
-            const unsigned ra = cbase + (unsigned)i * stride;
+            const unsigned ra = cbase + (unsigned)(i * 128);
             asm volatile("ds_read_b128 %0, %5\n\t"
                          "ds_read_b128 %1, %5 offset:1024\n\t"
                          "ds_read_b128 %2, %5 offset:2048\n\t"
@@ -1352,36 +1326,31 @@ struct ScatteredModel {
           auto landed = [&](RecRegs &R) {
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(R.c0), "+v"(R.c1), "+v"(R.c2), "+v"(R.ln3), "+v"(R.w2) : : "memory");
           };
-          auto use = [&](const RecRegs &R) {
+          auto use = [&](const RecRegs &R, int i) {
+            const int k = c * 64 + 8 * i + sub;
+            const double w2 = k < n_list ? R.w2 : 0.0;
+            kept += w2 != 0.0 ? 1 : 0;
             const double ln[4] = {R.c1.y, R.c2.x, R.c2.y, R.ln3};
-            fold(R.w2, R.c0.x - p[0], R.c0.y - p[1], R.c1.x - p[2], ln);
+            fold(w2, R.c0.x - p[0], R.c0.y - p[1], R.c1.x - p[2], ln);
           };
           RecRegs Ra, Rb;
           rd(Ra, 0);
           landed(Ra);
 #pragma unroll 1
-          for (int i = 0; i < iters; i += 2) { // (iters = 8 or 7: wave-uniform)
-            rd(Rb, i + 1 < iters ? i + 1 : iters - 1);
-            use(Ra);
+          for (int i = 0; i < 8; i += 2) {
+            rd(Rb, i + 1);
+            use(Ra, i);
             landed(Rb);
-            rd(Ra, i + 2 < iters ? i + 2 : iters - 1); // (the last one is read for nothing)
-            if (i + 1 < iters) use(Rb);
+            rd(Ra, i + 2 < 8 ? i + 2 : 7); // (the last one is read for nothing)
+            use(Rb, i + 1);
             landed(Ra);
           }
         }
       }
       InterpModel::wait_vm<0>();
     }
+    kept_out = group_sum(kept);
     SRT_PHASE(4);
-    if (uni((int)ps.nine) != 0 && __any(fit)) { // the helpers' partial sums join their point's group (lane sub == 0 of it takes them)
-      SRT_LDS double *help = (SRT_LDS double *)const_cast<SRT_LDS int *>(list) + HELP_OFF;
-      __syncthreads(); // (block == one wave: the ring's reads are over)
-      if (g == 7 && sub < 7) each_sum([&](double &v, int t) { help[sub * NSUM + t] = v; });
-      __syncthreads();
-      if (g < 7 && sub == 0) each_sum([&](double &v, int t) { v += help[g * NSUM + t]; });
-      __syncthreads(); // (the area is reused below)
-      fit = fit && g < 7;
-    }
     // combine the 8 lanes' partial sums and solve
     fi.v[0] = fi.v[1] = fi.v[2] = fi.v[3] = 0.0;
     if (__any(fit)) {
@@ -1440,41 +1409,395 @@ struct ScatteredModel {
     return fi;
   }
 
+  // ---- the fused form of sf_weights + sf_sums (SRT_SCAT_FUSED) -------------------------------------------------------------
+  // One pass over the list, 64 samples (a tile) at a time:
+  //   weigh   lane = sample: the sample is gathered again from the sample array (one trip ahead of its use), {r_c, cos, sin}
+  //           come from pass 1 (LDS side arrays; staging buffer for a long list), the eight half-weights as in sf_weights (the same
+  //           series, row by row, the same fallbacks) -- and the finished 128-byte record goes into the tile in LDS;
+  //   sum     lane = (point g, 1 of 8): the group folds the tile's records into its normal equations, as sf_sums does from its ring.
+  // Records behind the list's end carry zero weights (and the last sample's coordinates: finite), so the sums test no index; the
+  // samples a point keeps above the weight mask are counted where the weights are made (one compare per point and sample, the
+  // count itself scalar).  The running sums stay in registers across the weighing code: at two waves per SIMD that is 150 of the
+  // 256, so the series run over the points in two halves there (SRT_SCAT_CHAIN_SPLIT).
+#ifndef SRT_SCAT_CHAIN_SPLIT
+#define SRT_SCAT_CHAIN_SPLIT (SRT_SCAT_WAVES == 2)
+#endif
+  template <int J>
+  __device__ __noinline__ Fit4 sf_fused(const double (&p_in)[3], bool live, unsigned long long livemask, int npts, int n_list,
+                                        SRT_LDS const int *list, double *rec_flat, double dmax6, double d7, bool p7near,
+                                        int &kept_out) const {
+    const ScatteredModel M = uniform_copy();
+    Fit4 fi;
+    const double p[3] = {p_in[0], p_in[1], p_in[2]};
+    const double radius = M.radius;
+    SRT_AS1 double *const rec = (SRT_AS1 double *)rec_flat;
+    const int lane = threadIdx.x, g = lane >> 3, sub = lane & 7;
+    const double r2 = radius * radius, pi_R = PI / radius, reps = radius * 5.0e-16;
+    constexpr bool usemask = true;
+    SRT_PHASE_BEGIN(list);
+    SRT_LDS const Pass1Out *o = pass1_out(list);
+    double hin8[8], pg[8][3];
+    bool fit8[8], lv8[8];
+    int kept_c[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // wave-uniform
+#pragma unroll
+    for (int gg = 0; gg < 8; ++gg) {
+      hin8[gg] = uni(o->hin8[gg]);
+      lv8[gg] = (livemask >> (8 * gg)) & 1ull;
+      fit8[gg] = lv8[gg] && gg < npts && uni(o->cnt8[gg]) >= J;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) pg[gg][k] = from_lane(p[k], 8 * gg);
+    }
+    const bool fit = live && o->cnt8[g] >= J;
+    double eta8[8], etamax6 = 0.0;
+#pragma unroll
+    for (int gg = 0; gg < 8; ++gg) {
+      eta8[gg] = fdiv(hin8[0] - hin8[gg], hin8[gg]);
+      if (gg < 7 && fit8[gg]) etamax6 = fmax(etamax6, fabs(eta8[gg]));
+    }
+    const double eta7 = fit8[7] ? fabs(eta8[7]) : 0.0;
+    const bool base_ok = M.exact != 1 && uni(o->cnt8[0]) >= 1 && hin8[0] > 0.0 && etamax6 <= 1.0e-3;
+    const double sh = base_ok ? fm::exp_any(-1.1 * fm::log_pos(hin8[0] * 0.25)) : 0.0; // (h_c / 4)**-1.1: u_c = a sh
+    const double da3[3] = {pg[1][0] - pg[0][0], pg[3][1] - pg[0][1], pg[5][2] - pg[0][2]};
+    const double mda3[3] = {pg[2][0] - pg[0][0], pg[4][1] - pg[0][1], pg[6][2] - pg[0][2]};
+    const double o7[3] = {pg[7][0] - pg[0][0], pg[7][1] - pg[0][1], pg[7][2] - pg[0][2]};
+    const double o7sq = o7[0] * o7[0] + o7[1] * o7[1] + o7[2] * o7[2];
+    const double pc[3] = {pg[0][0], pg[0][1], pg[0][2]};
+    const Side2 side = side2_of(list, n_list);
+    // ---- the running sums (as sf_sums)
+    constexpr int NT = J * (J + 1) / 2;
+    constexpr bool O3 = J == 20;
+    double A[(O3 || J == 10) ? 1 : NT], b[O3 ? 1 : J][4];
+    double Mm[J == 10 ? Moments::N : 1];
+    typename std::conditional<O3, Sums20, int>::type S20;
+    if constexpr (O3) S20.zero();
+#pragma unroll
+    for (int t = 0; t < ((O3 || J == 10) ? 1 : NT); ++t) A[t] = 0.0;
+#pragma unroll
+    for (int t = 0; t < (J == 10 ? Moments::N : 1); ++t) Mm[t] = 0.0;
+#pragma unroll
+    for (int a = 0; a < (O3 ? 1 : J); ++a)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) b[a][s] = 0.0;
+    auto fold = [&](double w2, double d0, double d1, double d2, const double (&ln)[4]) {
+      if constexpr (O3) {
+        S20.fold(w2, d0, d1, d2, ln);
+      } else if constexpr (J == 10) {
+        const double dd[3] = {d0, d1, d2};
+        double wm[Moments::LOW], m[10];
+        wm[0] = w2;
+        Moments::monomials_from(wm, dd, std::make_integer_sequence<int, Moments::LOW - 1>{});
+#pragma unroll
+        for (int i = 0; i < Moments::LOW; ++i) Mm[i] += wm[i];
+        Moments::fold_leaves(Mm, wm, dd, std::make_integer_sequence<int, Moments::N - Moments::LOW>{});
+        Moments::firsts(wm, m, std::make_integer_sequence<int, 10>{}); // w m_a
+#pragma unroll
+        for (int a = 0; a < 10; ++a)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) b[a][s] += m[a] * ln[s];
+      } else {
+        double m[J];
+        monomials<J>(d0, d1, d2, m);
+        int t = 0;
+#pragma unroll
+        for (int a = 0; a < J; ++a) {
+          double wa = w2 * m[a];
+#pragma unroll
+          for (int cI = a; cI < J; ++cI) A[t++] += wa * m[cI];
+#pragma unroll
+          for (int s = 0; s < 4; ++s) b[a][s] += wa * ln[s];
+        }
+      }
+    };
+    // ---- the eight half-weights of one sample (sf_weights' arithmetic; w8[] out)
+    auto weigh = [&](const double q0, const double q1, const double q2, const double rc, const double ca, const double sa, double (&w8)[8]) {
+      const double dc[3] = {q0 - pc[0], q1 - pc[1], q2 - pc[2]};
+      const double ssc = dc[0] * dc[0] + dc[1] * dc[1] + dc[2] * dc[2];
+      const double xr = rc + reps;
+      const double a11 = xr * fm::exp_any(0.1 * fm::log_pos(xr));
+      const double inv = fdiv(1.0, xr), inv2 = inv * inv, hinv = 0.5 * inv;
+      const double u = a11 * sh;
+      const double E = fm::exp_any(-u);
+      double tb6 = dmax6 * inv, tb7 = d7 * inv;
+      tb6 = tb6 + etamax6 * (1.0 + tb6);
+      tb7 = tb7 + eta7 * (1.0 + tb7);
+      const bool dir6 = !(base_ok && tb6 <= 1.0e-3 && u * 1.2 * tb6 <= 1.0e-3);
+      const bool dir7 = dir6 || !(p7near && tb7 <= 1.0e-3 && u * 1.2 * tb7 <= 1.0e-3);
+      const double Eh = 0.5 * E, thr = 0.5 * 1.0e-16;
+      const double w0 = Eh * (0.5 + 0.5 * ca);
+      w8[0] = (fit8[0] && ssc < r2 && (w0 > thr || !usemask)) ? w0 : 0.0; // strictly inside (kdtree_mod.f95:171)
+      w8[7] = 0.0;
+      // chains FIRST .. FIRST + NQ - 1 (chain j = point j + 1), row by row with the order pinned (see sf_weights)
+      auto chains = [&](auto first, auto nq) {
+        constexpr int F0 = decltype(first)::value, NQ = decltype(nq)::value;
+#define SF_ROW(dst, expr)                                                                                              \
+  _Pragma("unroll") for (int j = 0; j < NQ; ++j) dst[j] = expr;                                                        \
+  _Pragma("unroll") for (int j = 0; j < NQ; ++j) asm volatile("" : "+v"(dst[j]))
+        double t[NQ], tin[NQ], pl[NQ], dr[NQ], au[NQ], X[NQ], cd[NQ], sd[NQ];
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+          const int jj = F0 + j;
+          if (jj < 6) {
+            const double dl = (jj & 1) ? mda3[jj >> 1] : da3[jj >> 1];
+            const double x = fma(-2.0, dc[jj >> 1], dl);
+            t[j] = dl * x;
+            tin[j] = fma(dl, x, ssc);
+          } else {
+            t[j] = o7sq - 2.0 * (o7[0] * dc[0] + o7[1] * dc[1] + o7[2] * dc[2]);
+            tin[j] = ssc + t[j];
+          }
+        }
+        SF_ROW(au, t[j] * inv2); // eps
+        SF_ROW(pl, fma(au[j], 0.0546875, -0.078125));
+        SF_ROW(pl, fma(au[j], pl[j], 0.125));
+        SF_ROW(pl, fma(au[j], pl[j], -0.25));
+        SF_ROW(pl, fma(au[j], pl[j], 1.0));
+        SF_ROW(dr, t[j] * hinv); // (= (0.5 t) inv to the bit)
+        SF_ROW(dr, dr[j] * pl[j]);
+        SF_ROW(au, dr[j] * inv); // tau
+        SF_ROW(au, fma(au[j], 1.0 + eta8[F0 + j + 1], eta8[F0 + j + 1]));
+        SF_ROW(pl, fma(au[j], 0.0078375, -0.0165));
+        SF_ROW(pl, fma(au[j], pl[j], 0.055));
+        SF_ROW(pl, fma(au[j], pl[j], 1.1));
+        SF_ROW(au, au[j] * pl[j]); // (1 + tau)**1.1 - 1
+        SF_ROW(au, u * au[j]);     // du
+        SF_ROW(pl, fma(au[j], -1.0 / 120.0, 1.0 / 24.0));
+        SF_ROW(pl, fma(au[j], pl[j], -1.0 / 6.0));
+        SF_ROW(pl, fma(au[j], pl[j], 0.5));
+        SF_ROW(pl, fma(au[j], pl[j], -1.0));
+        SF_ROW(X, fma(au[j], pl[j], 1.0)); // exp(-du)
+        SF_ROW(dr, dr[j] * pi_R);          // da
+        SF_ROW(au, dr[j] * dr[j]);
+        SF_ROW(cd, fma(au[j], 1.0 / 24.0, -0.5));
+        SF_ROW(sd, fma(au[j], 1.0 / 120.0, -1.0 / 6.0));
+        SF_ROW(cd, fma(au[j], cd[j], 1.0));
+        SF_ROW(sd, fma(au[j], sd[j], 1.0));
+        SF_ROW(sd, dr[j] * sd[j]);
+        SF_ROW(sd, sa * sd[j]);
+        SF_ROW(X, Eh * X[j]);
+        SF_ROW(cd, fma(ca, cd[j], -sd[j]));
+        SF_ROW(cd, fma(cd[j], 0.5, 0.5));
+        SF_ROW(X, X[j] * cd[j]);
+#undef SF_ROW
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) w8[F0 + j + 1] = (fit8[F0 + j + 1] && tin[j] < r2 && (X[j] > thr || !usemask)) ? X[j] : 0.0;
+      };
+      using I0 = std::integral_constant<int, 0>;
+      using I3 = std::integral_constant<int, 3>;
+      using I4 = std::integral_constant<int, 4>;
+      if constexpr (SRT_SCAT_CHAIN_SPLIT != 0) {
+        chains(I0{}, I3{});
+        if (fit8[7]) chains(I3{}, I4{}); // (wave-uniform)
+        else chains(I3{}, I3{});
+      } else {
+        if (fit8[7]) chains(I0{}, std::integral_constant<int, 7>{}); // (wave-uniform)
+        else chains(I0{}, std::integral_constant<int, 6>{});
+      }
+      if (dir6 || (dir7 && fit8[7])) { // rare, per lane: etainv() itself at the points that cannot take the series
+#pragma unroll 1
+        for (int gg = 0; gg < 8; ++gg) {
+          if (gg < 7 && !dir6) continue;
+          double px = pg[0][0], py = pg[0][1], pz = pg[0][2], hg = hin8[0];
+          bool fg = fit8[0];
+#pragma unroll
+          for (int t = 1; t < 8; ++t) {
+            px = gg == t ? pg[t][0] : px, py = gg == t ? pg[t][1] : py, pz = gg == t ? pg[t][2] : pz;
+            hg = gg == t ? hin8[t] : hg;
+            fg = gg == t ? fit8[t] : fg;
+          }
+          const double e0 = q0 - px, e1 = q1 - py, e2 = q2 - pz;
+          const double ss = e0 * e0 + e1 * e1 + e2 * e2;
+          double e = (fg && ss < r2) ? 0.5 * M.etainv_at(ss, hg) : 0.0;
+          e = (usemask && !(e > thr)) ? 0.0 : e; // :316-317
+#pragma unroll
+          for (int t = 0; t < 8; ++t) w8[t] = gg == t ? e : w8[t];
+        }
+      }
+    };
+    // ---- the pass
+    SRT_LDS char *const tile = tile_of(list);
+    const int nchunk = (n_list + 63) >> 6; // wave-uniform
+    const bool any = __any(fit);
+    // (one tile ahead: the next tile's gather is in flight while this one is weighed and summed)
+    d2_t na = {0.0, 0.0}, nb = na, nc = na, nd = na, n4 = na, n5 = na;
+    auto fetch = [&](int k) {
+      const int kc = k < n_list ? k : n_list - 1;
+      const SRT_AS1 d2_t *q = (const SRT_AS1 d2_t *)(M.gpts() + (size_t)list[kc] * 8);
+      na = q[0], nb = q[1], nc = q[2], nd = q[3];
+      if (kc >= side.cap) {
+        n4 = *chunk(rec, 4, kc);
+        n5 = *chunk(rec, 5, kc);
+      }
+    };
+    if (any && nchunk > 0) fetch(lane);
+    const int slot = (g == 7) ? 15 : 8 + g;
+    const unsigned tile0 = (unsigned)(unsigned long long)tile + (unsigned)(sub * 16);
+    const unsigned slot_off = (unsigned)((slot >> 1) * 1024 + (slot & 1) * 8);
+#pragma unroll 1
+    for (int c = 0; c < nchunk && any; ++c) {
+      const int k = c * 64 + lane;
+      const int kc = k < n_list ? k : n_list - 1;
+      const d2_t qa = na, qb = nb, qc = nc, qd = nd, q4 = n4, q5 = n5;
+      double rc, ca, sa;
+      if (kc < side.cap) {
+        const d2_t cs = side.cs[kc];
+        ca = cs.x, sa = cs.y;
+        rc = side.rc[kc];
+      } else {
+        rc = q4.x, ca = q5.x, sa = q5.y;
+      }
+      if (c + 1 < nchunk) fetch(k + 64);
+      double w8[8];
+      weigh(qa.x, qa.y, qb.x, rc, ca, sa, w8);
+      if (k >= n_list) { // behind the list's end: no weight at any point
+#pragma unroll
+        for (int t = 0; t < 8; ++t) w8[t] = 0.0;
+      }
+#pragma unroll
+      for (int gg = 0; gg < 8; ++gg) kept_c[gg] += __popcll(__ballot(w8[gg] != 0.0));
+      {
+        SRT_LDS d2_t *tl = (SRT_LDS d2_t *)tile + lane;
+        tl[0] = qa;
+        tl[64] = qb;
+        tl[128] = qc;
+        tl[192] = d2_t{qd.x, 0.0};
+        tl[256] = d2_t{w8[0], w8[1]};
+        tl[320] = d2_t{w8[2], w8[3]};
+        tl[384] = d2_t{w8[4], w8[5]};
+        tl[448] = d2_t{w8[6], w8[7]};
+      }
+      __syncthreads(); // block == one wave: the tile written above is read by other lanes below
+      if (fit) {
+        struct RecRegs {
+          d2_t c0, c1, c2;
+          double ln3, w2;
+        };
+        auto rd = [&](RecRegs &R, int i) {
+          const unsigned ra = tile0 + (unsigned)(i * 128);
+          asm volatile("ds_read_b128 %0, %5\n\t"
+                       "ds_read_b128 %1, %5 offset:1024\n\t"
+                       "ds_read_b128 %2, %5 offset:2048\n\t"
+                       "ds_read_b64 %3, %5 offset:3072\n\t"
+                       "ds_read_b64 %4, %6"
+                       : "=&v"(R.c0), "=&v"(R.c1), "=&v"(R.c2), "=&v"(R.ln3), "=&v"(R.w2)
+                       : "v"(ra), "v"(ra + slot_off)
+                       : "memory");
+        };
+        auto landed = [&](RecRegs &R) {
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(R.c0), "+v"(R.c1), "+v"(R.c2), "+v"(R.ln3), "+v"(R.w2) : : "memory");
+        };
+        auto use = [&](const RecRegs &R) {
+          const double ln[4] = {R.c1.y, R.c2.x, R.c2.y, R.ln3};
+          fold(R.w2, R.c0.x - p[0], R.c0.y - p[1], R.c1.x - p[2], ln);
+        };
+        RecRegs Ra, Rb;
+        rd(Ra, 0);
+        landed(Ra);
+#pragma unroll 1
+        for (int i = 0; i < 8; i += 2) {
+          rd(Rb, i + 1);
+          use(Ra);
+          landed(Rb);
+          rd(Ra, i + 2 < 8 ? i + 2 : 7); // (the last one is read for nothing)
+          use(Rb);
+          landed(Ra);
+        }
+      }
+      __syncthreads(); // (the tile is rewritten next trip)
+    }
+    {
+      int kk = kept_c[0];
+#pragma unroll
+      for (int t = 1; t < 8; ++t) kk = g == t ? kept_c[t] : kk;
+      kept_out = kk;
+    }
+    SRT_PHASE(4);
+    // combine the 8 lanes' partial sums and solve (as sf_sums)
+    fi.v[0] = fi.v[1] = fi.v[2] = fi.v[3] = 0.0;
+    if (any) {
+      if constexpr (O3) {
+        S20.reduce([](double v) { return group_sum(v); });
+        if (fit) {
+          double f4[4];
+          if (S20.solve(f4) == 0) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) fi.v[s] = f4[s];
+          }
+        }
+      } else if constexpr (J == 10) {
+        SRT_LDS double *area = (SRT_LDS double *)const_cast<SRT_LDS int *>(list) + 80 * g; // (the list and the side arrays are dead by now)
+        static_assert(Moments::N == 35, "area layout: 35 moments, then 10 x 4 right-hand sums");
+        auto sumof = [&](auto ic) -> double {
+          constexpr int t = decltype(ic)::value;
+          if constexpr (t < 35) return Mm[t];
+          else if constexpr (t < 75) return b[(t - 35) >> 2][(t - 35) & 3];
+          else return 0.0;
+        };
+        auto pairs = [&](auto self, auto ic) -> void {
+          constexpr int t = decltype(ic)::value;
+          if constexpr (t < 75) {
+            const double v = group_sum2(sumof(std::integral_constant<int, t>{}), sumof(std::integral_constant<int, t + 1>{}));
+            if ((sub & 3) == ((t >> 1) & 3) && t + (sub >> 2) < 75) area[t + (sub >> 2)] = v;
+            self(self, std::integral_constant<int, t + 2>{});
+          }
+        };
+        pairs(pairs, std::integral_constant<int, 0>{});
+        __syncthreads(); // block == one wave: the totals written above are read by the group's other lanes below
+        if (fit) {
+          double f1;
+          if (solve10_parked(area, sub & 3, f1) == 0) fi.v[0] = fi.v[1] = fi.v[2] = fi.v[3] = f1; // (this lane's species only)
+        }
+        __syncthreads(); // (the area is list space again)
+      } else {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) A[t] = group_sum(A[t]);
+#pragma unroll
+        for (int a = 0; a < J; ++a)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) b[a][s] = group_sum(b[a][s]);
+        if (fit) {
+          double f4[4];
+          if (solve_fit<J>(A, b, f4) == 0) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) fi.v[s] = f4[s];
+          }
+        }
+      }
+    }
+    SRT_PHASE(5);
+    return fi;
+  }
+
   // pass 1 + weights in one out-of-line body (one call, one set of registers saved around it); returns whether this group's
   // fit exists: its point has at least J samples (else status 2: too few samples, lsinterp_mod.f95:262-264)
   template <int J>
   __device__ __noinline__ bool sf_prepare(const double (&p)[3], bool live, unsigned long long livemask, int npts, int n_list,
-                                          SRT_LDS const int *list, double *rec, double dmax6, double d7, bool p7near,
-                                          int padded_len) const {
+                                          SRT_LDS const int *list, double *rec, double dmax6, double d7, bool p7near) const {
     sf_pass1(p, livemask, npts, n_list, list, rec, dmax6, d7, p7near);
-    sf_weights<J>(p, live, livemask, npts, n_list, list, rec, dmax6, d7, p7near, true, padded_len);
+    if constexpr (!FUSED) sf_weights<J>(p, live, livemask, npts, n_list, list, rec, dmax6, d7, p7near, true);
     return live && pass1_out(list)->cnt8[threadIdx.x >> 3] >= J;
   }
-  // `redo`: some point threw out too many samples (fewer than J kept: "use them all", lsinterp_mod.f95:319-323), known once the
-  // weights are (kept8), i.e. before the pair loop: the caller serves this stencil on the own-list path, which carries that rule
-  // itself (wave-uniform; rare).  Also taken by a list whose padding would not fit the staging buffer.
+  // `redo`: some point threw out too many samples (fewer than J kept: "use them all", lsinterp_mod.f95:319-323).  The list, the
+  // side arrays and pass 1's results are gone by then (the pair loop's ring and the parked totals have overwritten them), so
+  // the caller serves this stencil on the own-list path, which carries that rule itself (wave-uniform; rare).
   template <int J>
   __device__ __forceinline__ Fit4 shared_fit(const double (&p)[3], bool live, unsigned long long livemask, int npts, int n_list,
                                              SRT_LDS const int *list, double *rec, double dmax6, double d7, bool p7near,
                                              bool &redo) const {
-    Fit4 fi;
-    fi.v[0] = fi.v[1] = fi.v[2] = fi.v[3] = 0.0;
-    const PairSplit ps(npts, n_list);
-    redo = ps.padded > REC_CAP;
-    if (redo) return fi;
-    bool fit = sf_prepare<J>(p, live, livemask, npts, n_list, list, rec, dmax6, d7, p7near, ps.padded);
-    const int g = threadIdx.x >> 3, sub = threadIdx.x & 7;
-    redo = __any(fit && pass1_out(list)->kept8[g] < J);
-    if (redo) return fi;
-    double ph[3] = {p[0], p[1], p[2]};
-    if (ps.nine) { // the helpers take their point's coordinates and its fit flag
-      const unsigned long long fitmask = __ballot(fit);
-      const int src = g == 7 ? 8 * sub : (int)threadIdx.x;
-#pragma unroll
-      for (int k = 0; k < 3; ++k) ph[k] = __shfl(p[k], src);
-      if (g == 7) fit = sub < 7 && ((fitmask >> (8 * sub)) & 1ull) != 0ull;
+    if constexpr (FUSED) {
+      if (n_list > FUSED_LIST_CAP) { // (wave-uniform) the list leaves the tile no room: the own-list path serves this stencil
+        redo = true;
+        Fit4 none;
+        none.v[0] = none.v[1] = none.v[2] = none.v[3] = 0.0;
+        return none;
+      }
     }
-    return sf_sums<J>(ph, fit, n_list, list, rec, ps);
+    const bool fit = sf_prepare<J>(p, live, livemask, npts, n_list, list, rec, dmax6, d7, p7near);
+    int kept = 0;
+    Fit4 fi;
+    if constexpr (FUSED) fi = sf_fused<J>(p, live, livemask, npts, n_list, list, rec, dmax6, d7, p7near, kept);
+    else fi = sf_sums<J>(p, fit, n_list, list, rec, kept);
+    redo = __any(fit && kept < J);
+    return fi;
   }
   // The own-list path: the stencil straddles a grid cell, is too wide for the series, or the shared list would not
   // fit: every group scans the rows of its own point (8 lists of LIST_CAP, processed in pieces if they overflow) and

@@ -3,7 +3,6 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
-#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <thread>
@@ -26,10 +25,7 @@ struct Grid {
   size_t id(int cx, int cy, int cz) const { return ((size_t)cz * dims[1] + cy) * dims[0] + cx; }
 };
 
-// subsort: within a cell, order the samples along a Morton curve of 16^3 sub-cells (ties: file order).  A query ball covers a
-// compact part of each of its cells, so its samples then sit in runs of neighbouring records: two of them per 128-byte line
-// instead of one, and the 64 lanes of a gather touch half as many lines.  Only the order of summation depends on it.
-void build_grid(const std::vector<double> &xyz, int n, double cell, const double lo[3], const double hi[3], Grid &g, bool subsort = false) {
+void build_grid(const std::vector<double> &xyz, int n, double cell, const double lo[3], const double hi[3], Grid &g) {
   g.inv = 1.0 / cell;
   size_t ncell = 1;
   for (int k = 0; k < 3; ++k) {
@@ -48,34 +44,6 @@ void build_grid(const std::vector<double> &xyz, int n, double cell, const double
   g.order.resize(n);
   std::vector<int> fill(g.start.begin(), g.start.end() - 1);
   for (int i = 0; i < n; ++i) g.order[fill[cid[i]]++] = i;
-  if (!subsort) return;
-  auto spread4 = [](unsigned v) { // 4 bits -> every third bit
-    v &= 15u;
-    v = (v | (v << 4)) & 0x0C3u;
-    v = (v | (v << 2)) & 0x249u;
-    return v;
-  };
-  std::vector<unsigned short> key(n);
-  for (int i = 0; i < n; ++i) {
-    unsigned k3[3];
-    for (int k = 0; k < 3; ++k) {
-      const double t = (xyz[3 * (size_t)i + k] - g.origin[k]) * g.inv;
-      int f = (int)std::floor((t - std::floor(t)) * 16.0);
-      k3[k] = (unsigned)(f < 0 ? 0 : (f > 15 ? 15 : f));
-    }
-    key[i] = (unsigned short)(spread4(k3[0]) | (spread4(k3[1]) << 1) | (spread4(k3[2]) << 2));
-  }
-  unsigned nthr = std::thread::hardware_concurrency();
-  nthr = nthr ? (nthr > 32 ? 32 : nthr) : 1;
-  if (n < 20000) nthr = 1;
-  auto sort_cells = [&](size_t c0, size_t c1) {
-    for (size_t c = c0; c < c1; ++c)
-      std::sort(g.order.begin() + g.start[c], g.order.begin() + g.start[c + 1],
-                [&](int a, int b) { return key[a] != key[b] ? key[a] < key[b] : a < b; });
-  };
-  std::vector<std::thread> th;
-  for (unsigned t = 0; t < nthr; ++t) th.emplace_back(sort_cells, ncell * t / nthr, ncell * (t + 1) / nthr);
-  for (auto &x : th) x.join();
 }
 } // namespace
 
@@ -278,9 +246,7 @@ bool build_scattered(const char *path, double window_scale, ScatteredHost &out, 
   if (!(out.radius > 0)) { err = "degenerate sample set (max nearest distance is zero)"; return false; }
   // query grid: cell edge = radius * cell_scale (>= the radius), samples sorted by cell
   Grid q;
-  // (SRT_SCATTERED_SUBSORT=0: plain cell order, for A/B)
-  const char *ss = getenv("SRT_SCATTERED_SUBSORT");
-  build_grid(xyz, n, out.radius * (cell_scale >= 1.0 ? cell_scale : 1.0), lo, hi, q, !(ss && ss[0] == '0'));
+  build_grid(xyz, n, out.radius * (cell_scale >= 1.0 ? cell_scale : 1.0), lo, hi, q);
   out.npts = n;
   out.inv_cell = q.inv;
   for (int k = 0; k < 3; ++k) {

@@ -103,3 +103,54 @@ def parse_ray_file(path):
         tail = [float(line[438 + 24 * i:462 + 24 * i]) for i in range(16)]
         rows.append(head + vals + [nspec] + tail)
     return np.array(rows)
+
+
+def oracle_grad_sensitivity(om, x, k, w, del_, eps=(4.0e-16, 1.5e-15)):
+    """Per-sample yardstick for the finite-difference gradients: what the ORACLE's own dFdk / dFdw / dFdx / right-hand side do
+    when k or x move by `eps` relative (two and seven ulps) -- the level at which any other summation order differs from the reference's.
+    Central differences with a 1e-8 relative step amplify that by 2^-53 / 1e-8 times the cancellation in F, which on real data
+    (ionospheric densities, states near a resonance where dF/dw passes through zero) is unbounded; a fixed bar would either
+    fail there or be loose everywhere.  Returns (base[n,14], yard[n,5]): yard columns = vector-relative change of dFdk, relative
+    change of dFdw, vector-relative change of dFdx, of dx/dt, of dk/dt; each the largest over eight perturbations."""
+    base = np.array([om.grad(a, b, c, del_) for a, b, c in zip(x, k, w)])
+    yard = np.zeros((len(w), 5))
+    for sx, sk in [q for e in eps for q in ((0.0, e), (0.0, -e), (e, 0.0), (-e, 0.0))]:
+        g = np.array([om.grad(a * (1.0 + sx), b * (1.0 + sk), c, del_) for a, b, c in zip(x, k, w)])
+        e = np.stack([vrel(g[:, 0:3], base[:, 0:3]), np.abs(g[:, 3] - base[:, 3]) / np.maximum(np.abs(base[:, 3]), 1e-300),
+                      vrel(g[:, 4:7], base[:, 4:7]), vrel(g[:, 7:10], base[:, 7:10]), vrel(g[:, 10:13], base[:, 10:13])], axis=1)
+        yard = np.maximum(yard, e)
+    return base, yard
+
+
+def grad_errors(g, ref):
+    """The five error columns of oracle_grad_sensitivity for outputs g against ref."""
+    return np.stack([vrel(g[:, 0:3], ref[:, 0:3]), np.abs(g[:, 3] - ref[:, 3]) / np.maximum(np.abs(ref[:, 3]), 1e-300),
+                     vrel(g[:, 4:7], ref[:, 4:7]), vrel(g[:, 7:10], ref[:, 7:10]), vrel(g[:, 10:13], ref[:, 10:13])], axis=1)
+
+
+def within_sensitivity(err, yard, floor, factor=10.0, outliers=0.01):
+    """err[n] <= factor * max(yard[n], floor) for all but `outliers` of the samples (the yardstick is four random draws per
+    sample: a handful of random draws).  Returns (ok, text)."""
+    bound = factor * np.maximum(yard, floor)
+    bad = err > bound
+    txt = "%d / %d over their bound (worst ratio %.3g; err max %.3g, yard max %.3g, floor %.3g)" % (
+        bad.sum(), len(err), float(np.max(err / bound)), err.max(), yard.max(), floor)
+    return bad.mean() <= outliers, txt
+
+
+def oracle_step_sensitivity(om, args, dt, del_, eps=(4.0e-16, 1.5e-15, 6.0e-15)):
+    """Per-sample yardstick for one RK step (the three outputs rk4 / rkf45 4th / 5th order, 7 numbers each): what the oracle's own
+    step does when the state moves by `eps` relative.  Returns (base[n,21], yard[n,3,2]): vector-relative change of position and of
+    k for each of the three outputs, the largest over twelve perturbations (a step that crosses a discontinuity of the table is
+    chaotic: one draw may miss what the next one shows)."""
+    base = np.array([om.step(a, d, del_) for a, d in zip(args, dt)])
+    yard = np.zeros((len(dt), 3, 2))
+    for sx, sk in [q for e in eps for q in ((0.0, e), (0.0, -e), (e, 0.0), (-e, 0.0))]:
+        a2 = np.array(args, dtype=np.float64, copy=True)
+        a2[:, 0:3] *= (1.0 + sx)
+        a2[:, 3:6] *= (1.0 + sk)
+        g = np.array([om.step(a, d, del_) for a, d in zip(a2, dt)])
+        for i, o in enumerate((0, 7, 14)):
+            yard[:, i, 0] = np.maximum(yard[:, i, 0], vrel(g[:, o:o + 3], base[:, o:o + 3]))
+            yard[:, i, 1] = np.maximum(yard[:, i, 1], vrel(g[:, o + 3:o + 6], base[:, o + 3:o + 6]))
+    return base, yard

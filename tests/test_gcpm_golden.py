@@ -195,34 +195,63 @@ def test_gpu_interp_g0_on_the_gcpm_grid(gc, gpu_interp):
 
 
 @gpu
-def test_gpu_interp_g1_g2_g3_on_the_gcpm_grid(gc, gpu_interp):
+def test_gpu_interp_g1_g2_g3_on_the_gcpm_grid(gc, gpu_interp, oracle_interp):
     from conftest import G3_INTERP_BARS
 
     g = gpu_interp
     rows, ref = gc["g1_interp_in"], gc["g1_interp_out"]
     out = g.dispersion(rows[:, 0:3], rows[:, 3:6], rows[:, 6])
     assert rel(out[:, 1:6], ref[:, 1:6]).max() <= 1e-10
+    # G2 against the reference's outputs.  Bars per sample: 10 x the larger of the analytic grid's bar and the ORACLE's own change
+    # under a two-ulp shift of the state (conftest.oracle_grad_sensitivity) -- the launch set scaled by 0.78 holds states below
+    # the surface, where the table is the floor ln 1e-6 (a vacuum: dF/dw ~ 1e-12 is rounding noise, the reference moves by 100 %
+    # under that shift) and states in the F2 layer where F cancels to twelve digits
+    from conftest import grad_errors, oracle_grad_sensitivity, within_sensitivity
+
     gin, ref = gc["g2_interp_in"], gc["g2_interp_out"]
     out = g.gradients(gin[:, 0:3], gin[:, 3:6], gin[:, 6], 1e-6)
-    ek_, ew_ = vrel(out[:, 0:3], ref[:, 0:3]), rel(out[:, 3], ref[:, 3])
-    ex, ev, ek = vrel(out[:, 4:7], ref[:, 4:7]), vrel(out[:, 7:10], ref[:, 7:10]), vrel(out[:, 10:13], ref[:, 10:13])
-    msg = "dFdk max %.3g; dFdw max %.3g; dFdx median %.3g p95 %.3g; dx/dt max %.3g; dk/dt median %.3g p95 %.3g" % (
-        ek_.max(), ew_.max(), np.median(ex), np.percentile(ex, 95), ev.max(), np.median(ek), np.percentile(ek, 95))
+    base, yard = oracle_grad_sensitivity(oracle_interp, gin[:, 0:3], gin[:, 3:6], gin[:, 6], 1e-6)
+    assert np.array_equal(base, ref[:, :base.shape[1]])                    # the oracle IS the reference here
+    err = grad_errors(out, ref)
+    well = np.all(yard <= 1e-7, axis=1)                                    # well-conditioned states: the analytic grid's bars, as is
+    assert well.sum() >= 80
+    msg = "well-conditioned (%d): dFdk max %.3g; dFdw max %.3g; dFdx median %.3g p95 %.3g; dx/dt max %.3g; dk/dt median %.3g p95 %.3g" % (
+        well.sum(), err[well, 0].max(), err[well, 1].max(), np.median(err[well, 2]), np.percentile(err[well, 2], 95), err[well, 3].max(),
+        np.median(err[well, 4]), np.percentile(err[well, 4], 95))
     print(msg)
-    assert ek_.max() <= 1e-7 and ew_.max() <= 1e-6, msg
-    assert np.median(ex) <= 1e-7 and np.percentile(ex, 95) <= 1e-5, msg
-    assert ev.max() <= 1e-6, msg
-    assert np.median(ek) <= 1e-6 and np.percentile(ek, 95) <= 2e-5, msg
+    assert err[well, 0].max() <= 1e-7 and err[well, 1].max() <= 1e-6, msg
+    assert np.median(err[well, 2]) <= 1e-7 and np.percentile(err[well, 2], 95) <= 1e-5, msg
+    assert err[well, 3].max() <= 1e-6, msg
+    assert np.median(err[well, 4]) <= 1e-6 and np.percentile(err[well, 4], 95) <= 2e-5, msg
+    for col, (name, floor) in enumerate((("dFdk", 1e-8), ("dFdw", 1e-7), ("dFdx", 1e-6), ("dx/dt", 1e-7), ("dk/dt", 2e-6))):
+        fin = np.isfinite(yard[:, col]) & np.isfinite(err[:, col])
+        ok, txt = within_sensitivity(err[fin, col], yard[fin, col], floor)
+        assert ok, "%s: %s" % (name, txt)
+    # G3: one RK step.  The analytic grid's bars (conftest.G3_INTERP_BARS: the reference's own sensitivity THERE) for the states
+    # where the oracle moves by less than those bars under a two-ulp shift; every state within 10 x the larger of its own
+    # yardstick and the bar (a step that starts under the surface crosses the 41-e-fold jump of the table: the reference's own
+    # position moves by tens of per cent under that shift)
+    from conftest import oracle_step_sensitivity
+
     sin, ref = gc["g3_interp_in"], gc["g3_interp_out"]
     out = g.rk_step(sin[:, 0:7], sin[:, 7], 1e-6)
+    sbase, syard = oracle_step_sensitivity(oracle_interp, sin[:, 0:7], sin[:, 7], 1e-6)
+    assert np.array_equal(sbase, ref, equal_nan=True)                      # the oracle IS the reference here
     b = G3_INTERP_BARS
-    for o in (0, 7, 14):
+    for i, o in enumerate((0, 7, 14)):
         ex, ek = vrel(out[:, o:o + 3], ref[:, o:o + 3]), vrel(out[:, o + 3:o + 6], ref[:, o + 3:o + 6])
-        msg = "step output %d: pos median %.3g max %.3g; k median %.3g p90 %.3g max %.3g" % (
-            o, np.median(ex), ex.max(), np.median(ek), np.percentile(ek, 90), ek.max())
+        well = (syard[:, i, 0] <= b["pos_median"]) & (syard[:, i, 1] <= b["k_median"])
+        msg = "step output %d: %d well-conditioned of %d: pos median %.3g max %.3g; k median %.3g p90 %.3g max %.3g; all: pos max %.3g k max %.3g" % (
+            o, well.sum(), len(well), np.median(ex[well]), ex[well].max(), np.median(ek[well]), np.percentile(ek[well], 90), ek[well].max(),
+            ex.max(), ek.max())
         print(msg)
-        assert np.median(ex) <= b["pos_median"] and ex.max() <= b["pos_max"], msg
-        assert np.median(ek) <= b["k_median"] and np.percentile(ek, 90) <= b["k_p90"] and ek.max() <= b["k_max"], msg
+        assert well.sum() >= 30, msg
+        assert np.median(ex[well]) <= b["pos_median"] and ex[well].max() <= b["pos_max"], msg
+        assert np.median(ek[well]) <= b["k_median"] and np.percentile(ek[well], 90) <= b["k_p90"] and ek[well].max() <= b["k_max"], msg
+        for err, yard, floor, name in ((ex, syard[:, i, 0], b["pos_max"], "position"), (ek, syard[:, i, 1], b["k_max"], "k")):
+            fin = np.isfinite(err) & np.isfinite(yard)
+            ok, txt = within_sensitivity(err[fin], yard[fin], floor, outliers=0.03)
+            assert ok, "step output %d, %s: %s" % (o, name, txt)
 
 
 @gpu

@@ -214,3 +214,51 @@ def test_rccl_branch_world_size_one(pipelined):
     assert nbytes == 0  # nothing travels to the only rank
     assert np.array_equal(nrows2, nrows.cpu().numpy()) and np.array_equal(stop2, stop.cpu().numpy())
     assert np.array_equal(packed2.view(np.uint64), pt.cpu().numpy().view(np.uint64))
+
+
+def _run_bench(nranks, port, rays=6007):
+    import json
+    import subprocess
+
+    args = ["--gpus", str(nranks), "--steps", "2", "--warmup", "1", "--workload", "interp4m", "--rays", str(rays), "--grid", "24",
+            "--maxsteps", "96", "--traffic", "off", "--other-configs", "0", "--cpu-seconds", "0", "--damping-rays", "0"]
+    cmd = [sys.executable]
+    if nranks > 1:
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks), "--master-addr", "127.0.0.1",
+                "--master-port", str(port)]
+    cmd += [os.path.join(ROOT, "bench.py")] + args
+    env = dict(os.environ, SRT_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints ONE JSON line, the other ranks none: %r" % r.stdout[-500:]
+    return json.loads(lines[0])
+
+
+def test_three_rank_rehearsal_through_bench_py():
+    """`bench.py --gpus N` as the driver launches it (python -m torch.distributed.run, one process per rank, rendezvous on
+    127.0.0.1), rehearsed on the one card: 3 ranks (the box's process guard kills a run with more than 6 processes on the GPU:
+    this test runner and the launcher's agent are two of them -- a 5-rank version of this test was killed at 7) with the gloo
+    backend standing in for RCCL (SRT_BENCH_BACKEND=gloo folds the ranks onto cuda:0; RCCL itself refuses two ranks on one
+    device), a tiny grid, a launch set that does not divide (6007 rays: shards of 2003, 2002, 2002).
+    Through bench.py's own code: parallel.trace_sharded (counts all_gather, grouped send / recv of the packed rows to rank 0),
+    the barrier-bracketed timed region, the max-over-ranks reduction, the pipelined pass.  The printed line must name 3 GPUs,
+    carry the multi_gpu fields, and its rows_checksum -- a position-weighted sum over the bits of every gathered row, row count
+    and stop code -- must equal the one-GPU run's of the same launch set."""
+    one = _run_bench(1, 0)
+    many = _run_bench(3, _free_port())
+    assert one["n_gpus"] == 1 and many["n_gpus"] == 3 and many["scaling"] == "strong"
+    assert many["config"]["total_rays"] == 6007 and many["config"]["rays_per_gpu"] == 2003
+    mg = many["multi_gpu"]
+    for key in ("gather_ms", "pack_ms", "kernel_ms_max_over_ranks", "gather_bytes_into_rank0", "gather_GBs", "pipelined"):
+        assert key in mg, key
+    assert mg["gather_ms"] > 0 and mg["pack_ms"] > 0 and mg["kernel_ms_max_over_ranks"] > 0
+    assert mg["pipelined"]["ms_per_step"] is not None, mg["pipelined"]
+    acc1, acc5 = one["detail"]["accepted_steps_per_launch_all_ranks"], many["detail"]["accepted_steps_per_launch_all_ranks"]
+    assert acc1 == acc5 and acc1 > 100000
+    assert one["detail"]["packed_rows"] == many["detail"]["packed_rows"]
+    assert one["detail"]["rows_checksum"] == many["detail"]["rows_checksum"]
+    # rank 0 received every other shard's packed rows (160 B each) + nrows and stop codes (8 B per ray)
+    rows0 = mg["gather_bytes_into_rank0"]
+    assert 0 < rows0 < many["detail"]["packed_rows"] * 160 + 6007 * 8
+    assert many["value"] > 0 and many["steps"] == 2 and many["warmup"] == 1

@@ -354,24 +354,29 @@ def test_value_parity_on_the_256_grid(interp256_model, oracle256):
     x, k, w = pts[ok], kd[ok] * kmag[ok, None], w[ok]
     gg = g.gradients(x, k, w, 1e-6)
     og = np.array([o.grad(a, b, c, 1e-6) for a, b, c in zip(x, k, w)])
-    # The 16^3 bars hold for the bulk; the maxima get a decade more here.  This point set reaches the outermost cells of the
-    # table (10 R_E, N_e four decades below the launch region's), where F = A n^4 - B n^2 + RLP is a difference of terms that
-    # cancel to more digits, and dF/dk, dF/dw are central differences with a 1e-8 RELATIVE step: one ulp of F moves them by
-    # 2^-53 / 1e-8 times that cancellation (first GPU run of this test: dF/dk worst 1.12e-7 on 968 points, 99 % under 1e-8).
-    ek_ = vrel(gg[:, 0:3], og[:, 0:3])
-    ew_ = rel(gg[:, 3], og[:, 3])
-    ex = vrel(gg[:, 4:7], og[:, 4:7])
-    ev = vrel(gg[:, 7:10], og[:, 7:10])
-    ek = vrel(gg[:, 10:13], og[:, 10:13])
-    msg = "dFdk p99 %.3g max %.3g; dFdw p99 %.3g max %.3g; dFdx median %.3g p95 %.3g; dx/dt p99 %.3g max %.3g; dk/dt median %.3g " \
-          "p95 %.3g" % (np.percentile(ek_, 99), ek_.max(), np.percentile(ew_, 99), ew_.max(), np.median(ex), np.percentile(ex, 95),
-                       np.percentile(ev, 99), ev.max(), np.median(ek), np.percentile(ek, 95))
+    # Bars per sample: 10 x the larger of a floor and the ORACLE's own change under a two-ulp shift of the state
+    # (conftest.oracle_grad_sensitivity).  This point set reaches the outermost cells of the table (10 R_E, N_e four decades below
+    # the launch region's), where dF/dk, dF/dw -- central differences with a 1e-8 RELATIVE step -- amplify one ulp of F by
+    # 2^-53 / 1e-8 times F's cancellation (first GPU run: dF/dw worst 2.2e-4, 99 % under 4e-5).  The well-conditioned states keep
+    # the 16^3 bars as they are.
+    from conftest import grad_errors, oracle_grad_sensitivity, within_sensitivity
+
+    _, yard = oracle_grad_sensitivity(o, x, k, w, 1e-6)
+    err = grad_errors(gg, og)
+    well = np.all(yard <= 1e-7, axis=1)
+    msg = "well-conditioned %d of %d: dFdk max %.3g; dFdw max %.3g; dFdx median %.3g p95 %.3g; dx/dt max %.3g; dk/dt median %.3g p95 %.3g" % (
+        well.sum(), len(well), err[well, 0].max(), err[well, 1].max(), np.median(err[well, 2]), np.percentile(err[well, 2], 95),
+        err[well, 3].max(), np.median(err[well, 4]), np.percentile(err[well, 4], 95))
     print(msg)
-    assert np.percentile(ek_, 99) <= 1e-7 and ek_.max() <= 1e-6, msg
-    assert np.percentile(ew_, 99) <= 1e-6 and ew_.max() <= 1e-5, msg
-    assert np.median(ex) <= 1e-7 and np.percentile(ex, 95) <= 1e-5, msg
-    assert np.percentile(ev, 99) <= 1e-6 and ev.max() <= 1e-5, msg
-    assert np.median(ek) <= 1e-6 and np.percentile(ek, 95) <= 2e-5, msg
+    assert well.sum() >= 300, msg
+    assert err[well, 0].max() <= 1e-7 and err[well, 1].max() <= 1e-6, msg
+    assert np.median(err[well, 2]) <= 1e-7 and np.percentile(err[well, 2], 95) <= 1e-5, msg
+    assert err[well, 3].max() <= 1e-6, msg
+    assert np.median(err[well, 4]) <= 1e-6 and np.percentile(err[well, 4], 95) <= 2e-5, msg
+    for col, (name, floor) in enumerate((("dFdk", 1e-8), ("dFdw", 1e-7), ("dFdx", 1e-6), ("dx/dt", 1e-7), ("dk/dt", 2e-6))):
+        fin = np.isfinite(yard[:, col]) & np.isfinite(err[:, col])
+        ok, txt = within_sensitivity(err[fin, col], yard[fin, col], floor)
+        assert ok, "%s: %s" % (name, txt)
 
 
 def test_full_size_config4_interp_4m_shards(interp256_model):

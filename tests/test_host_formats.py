@@ -313,3 +313,29 @@ def test_ray_file_edge_cases_of_the_record_head(tmp_path):
     api.write_ray_file(str(ap), (4, wl.QS, wl.MS), p, w0[:1], rows[:1], nrows[:1], stop[:1], raynum0=2, append=True)
     r = api.read_ray_file(str(ap))
     assert r["raynum"].tolist() == [1, 2, 2] and r["kept"].tolist() == [3, 2, 3] and r["w0"].tolist() == [1e4, 2e4, 1e4]
+
+
+def test_writers_reproduce_the_reference_builders_files_byte_for_byte(tmp_path):
+    """What `raytracer --buildgrid=1` / `--buildsamples=1` write (srt_grid_file_write, srt_points_file_write) against files the
+    reference's OWN producers wrote (tests/golden/make_builder_layout_golden.py: gcpm_dens_model_buildgrid with --compder=1 on
+    3 x 4 x 5 nodes, gcpm_dens_model_buildgrid_random with 60 samples): read by the library's readers, written back by its writers,
+    the bytes must be the same -- header records, field widths, exponent digits, one value per record, block order."""
+    ref = os.path.join(GOLDEN_DIR, "builder_grid_3x4x5_compder1.txt")
+    g = api.read_grid_file(ref)
+    assert g["F"].shape == (5, 4, 3, 4) and g["derivs"] is not None and len(g["derivs"]) == 7
+    out = str(tmp_path / "grid.txt")
+    api.write_grid_file(out, g["F"], g["bounds"], g["qs"], g["ms"], derivs=g["derivs"])
+    assert open(out, "rb").read() == open(ref, "rb").read()
+    # ... and the same file with compder = 0 is the reference's first 4 + 240 records
+    api.write_grid_file(out, g["F"], g["bounds"], g["qs"], g["ms"])
+    want = open(ref).read().split("\n")[:4 + 240]
+    want[0] = "%10d" % 0 + want[0][10:]
+    assert open(out).read() == "\n".join(want) + "\n"
+    ref = os.path.join(GOLDEN_DIR, "builder_samples_60.txt")
+    tok = open(ref).read().split()
+    rec = np.array([float(t) for t in tok[15:]]).reshape(-1, 7)
+    assert len(rec) == 60
+    out = str(tmp_path / "pts.txt")
+    api.write_points_file(out, rec, np.array([float(t) for t in tok[1:7]]), np.array([float(t) for t in tok[7:11]]),
+                          np.array([float(t) for t in tok[11:15]]))
+    assert open(out, "rb").read() == open(ref, "rb").read()
