@@ -103,6 +103,17 @@ int srt_model_create_interp(int nspec, int nx, int ny, int nz, const double boun
  * parameters are the --scattered_interp_* flags of raytracer_driver.f95:690-728 */
 int srt_model_create_scattered_file(const char *ptsfile, int yearday, int msec, double window_scale,
                                     int order, int exact, double local_window_scale, srt_model **out);
+/* The same with the reference's kd-tree ROOT reproduced (opt-in, for diffing against a reference binary): the reference's
+ * kdtree_nearest starts its search at the tree's root (kdtree_mod.f95:386-444), so for the ONE sample that is the root
+ * "the nearest other sample" is the sample itself -- its stored spacing stays 0 and does not enter maxnearest
+ * (scattered_interp_dens_model_adapter.f95:167-203).  Every lookup whose search window holds that sample sees
+ * it.  Which sample it is comes from the reference build's RNG (randperm, :137-140), so the caller names it:
+ * root_sample = its 0-based record number in the file (the reference prints nothing; a harness linked against its modules can
+ * ask the tree -- oracle/ref_harness.f95 --mode=scatroot), -1 = none = srt_model_create_scattered_file, which stores the true
+ * distance for every sample (the documented default). */
+int srt_model_create_scattered_file_root(const char *ptsfile, int yearday, int msec, double window_scale,
+                                         int order, int exact, double local_window_scale, int64_t root_sample,
+                                         srt_model **out);
 /* The step before the path: sample a model's funcPlasmaParams on a regular nx x ny x nz grid in
  * log space ON THE DEVICE -- gcpm_dens_model_buildgrid.f95:160-300 with any model handle in place of GCPM.
  * compder = 1 adds the seven explicit finite-difference blocks (d = 1e-3*|pos|, :197-296); compder = 0 leaves the

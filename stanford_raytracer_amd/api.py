@@ -79,6 +79,8 @@ def lib():
                                                           C.POINTER(vp)]
     L.srt_model_create_scattered_file.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int,
                                                   C.c_double, C.POINTER(vp)]
+    L.srt_model_create_scattered_file_root.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int,
+                                                       C.c_double, C.c_int64, C.POINTER(vp)]
     L.srt_model_set_field.argtypes = [vp, C.c_int, C.c_int, C.c_char_p]
     L.srt_model_set_tsyganenko_params.argtypes = [vp, dp]
     L.srt_model_destroy.argtypes = [vp]
@@ -201,10 +203,12 @@ class Model:
 
     @classmethod
     def scattered_file(cls, ptsfile, yearday=2010001, msec=0, window_scale=1.5, order=2, exact=0,
-                       local_window_scale=5.0):
+                       local_window_scale=5.0, root_sample=-1):
+        """root_sample: 0-based record number of the sample at the root of the REFERENCE's kd-tree (its stored spacing stays
+        0 there, include/srt.h srt_model_create_scattered_file_root); -1 = the true distance for every sample."""
         h = C.c_void_p()
-        _check(lib().srt_model_create_scattered_file(os.fsencode(ptsfile), yearday, msec, window_scale, order,
-                                                     exact, local_window_scale, C.byref(h)))
+        _check(lib().srt_model_create_scattered_file_root(os.fsencode(ptsfile), yearday, msec, window_scale, order,
+                                                          exact, local_window_scale, int(root_sample), C.byref(h)))
         return cls(h)
 
     def build_grid(self, nx, ny, nz, bounds, compder=False):

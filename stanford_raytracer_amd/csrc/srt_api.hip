@@ -830,7 +830,14 @@ extern "C" int srt_model_create_interp_file(const char *gridfile, int yearday, i
 
 extern "C" int srt_model_create_scattered_file(const char *ptsfile, int yearday, int msec, double window_scale,
                                                int order, int exact, double local_window_scale, srt_model **out) {
+  return srt_model_create_scattered_file_root(ptsfile, yearday, msec, window_scale, order, exact, local_window_scale, -1, out);
+}
+
+extern "C" int srt_model_create_scattered_file_root(const char *ptsfile, int yearday, int msec, double window_scale,
+                                                    int order, int exact, double local_window_scale, int64_t root_sample,
+                                                    srt_model **out) {
   if (!ptsfile || !out) return srt_set_error(SRT_EINVAL, "null argument");
+  if (root_sample < -1) return srt_set_error(SRT_EINVAL, "root_sample must be -1 (none) or a 0-based record number");
   if (order < 0 || order > 3) // tabular_monomials covers degrees 0..3 (lsinterp_mod.f95:76-99); beyond: generate_monomials, not built
     return srt_set_error(SRT_EINVAL, "scattered_interp_order=%d: orders 0..3 are supported (the reference's generate_monomials orders, "
                                      "N >= 4, are not built: stay on the Fortran path for them)", order);
@@ -847,7 +854,8 @@ extern "C" int srt_model_create_scattered_file(const char *ptsfile, int yearday,
     const double v = atof(e);
     if (v >= 0.01 && v <= 1.0) bmargin = v;
   }
-  if (!srt_host::build_scattered(ptsfile, window_scale, h, err, 1.0 + bmargin)) return srt_set_error(SRT_EIO, "%s: %s", ptsfile, err.c_str());
+  if (!srt_host::build_scattered(ptsfile, window_scale, h, err, 1.0 + bmargin, (long long)root_sample))
+    return srt_set_error(SRT_EIO, "%s: %s", ptsfile, err.c_str());
   srt_model *m = new srt_model;
   m->kind = 4;
   m->nspec = h.nspec;

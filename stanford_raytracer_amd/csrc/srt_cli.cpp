@@ -103,7 +103,11 @@ static int make_model(int device, srt_model **out, double *del) {
     need(get_int("scattered_interp_exact", exact), "scattered_interp_exact");
     need(get_real("scattered_interp_local_window_scale", lws), "scattered_interp_local_window_scale");
     p.del = 1.0e-6;
-    CHECK(srt_model_create_scattered_file(file.c_str(), yearday, msec, ws, order, exact, lws, &m));
+    // ours (opt-in): --scattered_interp_root_sample=<record number, 1 = the file's first sample>: the sample at the root of the
+    // reference's kd-tree keeps a stored spacing of 0 there (kdtree_mod.f95:386-444); default: none
+    double root = 0;
+    get_real("scattered_interp_root_sample", root);
+    CHECK(srt_model_create_scattered_file_root(file.c_str(), yearday, msec, ws, order, exact, lws, (int64_t)floor(root) - 1, &m));
   } else {
     fprintf(stderr, "raytracer: --modelnum=%d is not on the accelerated path (1, 3, 4 are)\n", modelnum);
     return 2;
@@ -137,6 +141,7 @@ int main(int argc, char **argv) {
          "  model 3: --interp_interpfile --yearday --milliseconds_day --use_tsyganenko=0|1 --use_igrf=0|1\n"
          "  model 4: model 3 flags + --scattered_interp_window_scale --scattered_interp_order\n"
          "           --scattered_interp_exact --scattered_interp_local_window_scale\n"
+         "           [--scattered_interp_root_sample=N: record N of the file is the root of the reference's kd-tree (spacing 0)]\n"
          "  extra:   --device=N | --devices=0,1,..  --chunk_rays=N  --ray_order=0|1  --timing=1 (wall clock per phase)\n"
          "           --first_attempt_policy=1|0: error estimate of a ray's first adaptive attempt, where the reference reads an\n"
          "             unset variable: 1 (default) = from the k term alone, as the reference's gfortran build behaves;\n"

@@ -80,5 +80,6 @@ struct ScatteredHost {
 };
 // cell_scale: edge of the query grid's cells in units of the search radius (>= 1; the device's candidate blocks reach
 // radius * cell_scale from their centre and are built from the 27 cells around it)
-bool build_scattered(const char *path, double window_scale, ScatteredHost &out, std::string &err, double cell_scale = 1.0);
+bool build_scattered(const char *path, double window_scale, ScatteredHost &out, std::string &err, double cell_scale = 1.0,
+                     long long root_file_index = -1);
 } // namespace srt_host

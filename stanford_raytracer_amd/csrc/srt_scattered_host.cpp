@@ -113,7 +113,7 @@ bool write_points_file(const char *path, bool binary, int nspec, int64_t npts, c
   return ok;
 }
 
-bool build_scattered(const char *path, double window_scale, ScatteredHost &out, std::string &err, double cell_scale) {
+bool build_scattered(const char *path, double window_scale, ScatteredHost &out, std::string &err, double cell_scale, long long root_file_index) {
   std::vector<double> raw;
   int nspec = 0;
   if (is_binary_points(path)) {
@@ -241,6 +241,25 @@ bool build_scattered(const char *path, double window_scale, ScatteredHost &out, 
   }
   double maxnearest = 0.0;
   for (double v : maxn) maxnearest = std::max(maxnearest, v);
+  if (root_file_index >= 0) {
+    // opt-in: the reference's kd-tree root.  Its kdtree_nearest starts from the root, so for the ONE sample that is the root
+    // "nearest other sample" is the sample itself: its stored spacing stays 0 and never enters maxnearest
+    // (kdtree_mod.f95:386-444, scattered_interp_dens_model_adapter.f95:167-203; SURVEY A-12).  Which sample that is comes from
+    // the reference build's RNG (randperm); the caller names it by its position in the file.
+    int ri = -1;
+    for (int i = 0; i < n; ++i)
+      if (keep[i] == root_file_index) ri = i;
+    if (ri < 0) { err = "scattered root sample: no such record in the file (or it is a dropped duplicate)"; return false; }
+    const double *p = &xyz[3 * (size_t)ri];
+    if (p[0] * p[0] + p[1] * p[1] + p[2] * p[2] >= R_E * R_E) {
+      nn[ri] = 0.0;
+      maxnearest = 0.0;
+      for (int i = 0; i < n; ++i) {
+        const double *q = &xyz[3 * (size_t)i];
+        if (q[0] * q[0] + q[1] * q[1] + q[2] * q[2] >= R_E * R_E) maxnearest = std::max(maxnearest, nn[i]);
+      }
+    }
+  }
   out.maxnearest = maxnearest;
   out.radius = maxnearest * window_scale;
   if (!(out.radius > 0)) { err = "degenerate sample set (max nearest distance is zero)"; return false; }

@@ -18,7 +18,7 @@ def declared_symbols():
 def test_header_declares_the_boundary():
     syms = declared_symbols()
     for s in ("srt_trace_batch", "srt_trace_batch_device", "srt_plasma_params", "srt_model_create_ngo",
-              "srt_model_create_interp", "srt_model_create_interp_file", "srt_model_create_scattered_file",
+              "srt_model_create_interp", "srt_model_create_interp_file", "srt_model_create_scattered_file", "srt_model_create_scattered_file_root",
               "srt_write_ray_file", "srt_read_rays_file"):
         assert s in syms
 

@@ -331,3 +331,29 @@ def test_interp_file_supplied_derivatives(grid16, golden, tmp_path):
     o = oracle.Model.interp_file(gf)
     op = np.array([np.concatenate(o.plasma_params(p)) for p in x])
     assert rel(g[:, 4:8], op[:, 4:8]).max() <= 1e-11
+
+
+@pytest.mark.parametrize("key,kw", [("g0_scattered_out", {}), ("g0_o3_out", {"order": 3})])
+def test_scattered_root_switch_reproduces_the_reference_everywhere(golden, scat_o3, pointsfile, key, kw):
+    """The opt-in srt_model_create_scattered_file_root (CLI --scattered_interp_root_sample): with the sample at the root of the
+    REFERENCE's kd-tree named (tests/golden/scattered_o3_golden.npz: ref_root_index, asked of the reference's own tree), its
+    stored spacing is 0 as in the reference (kdtree_mod.f95:386-444) and EVERY lookup agrees with the reference's output --
+    including the ones whose window holds that sample, which test_g0_scattered_params has to leave to the oracle.  The search
+    radius (maxnearest x window_scale) is the reference's, bit for bit."""
+    from stanford_raytracer_amd import api
+
+    root = int(scat_o3["ref_root_index"])
+    m = api.Model.scattered_file(pointsfile, root_sample=root, **kw)
+    x, ref = golden["g0_scattered_x"], (scat_o3[key] if key == "g0_o3_out" else golden[key])
+    g = m.plasma_params(x)
+    ok = ref[:, 4] > 0
+    e = np.abs(g[ok, 4:8] - ref[ok, 4:8]) / ref[ok, 4:8]
+    assert e.max() <= 1e-9, e.max()
+    assert np.array_equal(g[~ok, 4:8], ref[~ok, 4:8])
+    # ... and the default build differs from it exactly at the lookups near that sample
+    d = api.Model.scattered_file(pointsfile, **kw).plasma_params(x)
+    near = np.linalg.norm(x - scat_o3["ref_root_point"], axis=1) < float(scat_o3["ref_maxnearest"]) * 1.5
+    moved = np.abs(d[:, 4] - g[:, 4]) > 1e-12 * np.abs(g[:, 4])
+    assert moved.any() and not np.any(moved & ~near)
+    with pytest.raises(api.SrtError):
+        api.Model.scattered_file(pointsfile, root_sample=10 ** 7)
