@@ -75,14 +75,39 @@ __device__ __forceinline__ void stencil_points(const double x[3], double del, do
   }
 }
 
+// One offset point of dispersion_relation_dFdx (raytracer.f95:239-262): the field at x +- d e_c, the Stix parameters of the
+// plasma there, the dispersion function.  ONE compiled body: in tail mode (below) another lane evaluates it for the ray's
+// lane and has to produce that lane's bits.
+template <class CM>
+__device__ __noinline__ double offset_F(const CM &cm, double px, double py, double pz, double N0, double N1, double N2, double N3,
+                                        double w, double n0, double n1, double n2) {
+  double Bp[3];
+  bfield(cm, px, py, pz, Bp);
+  const double Bp2 = Bp[0] * Bp[0] + Bp[1] * Bp[1] + Bp[2] * Bp[2];
+  const double Ns[4] = {N0, N1, N2, N3};
+  const Stix st = stix_parameters(cm.sp, w, Ns, sqrt(Bp2));
+  const double n[3] = {n0, n1, n2};
+  return dispersion_F(st, n, Bp, Bp2);
+}
+// Models whose launches end in a long tail of a few rays (config[1]: 27 of 100 k rays run to maxsteps, the mean ray stops
+// after 29 steps) spread the six offset evaluations of a right-hand side over idle lanes when at most 8 lanes of the wave
+// carry a ray: the launch then runs at one ray's sequential trip time, and those six chains in a row were a quarter of it.
+#ifndef SRT_NGO_SPREAD
+#define SRT_NGO_SPREAD 1 // (0: every right-hand side in the ray's own lane, for A/B)
+#endif
+template <class M>
+constexpr bool spread_rhs() { return SRT_NGO_SPREAD != 0 && std::is_same<M, NgoModel>::value; }
+
 // raytracer_evalrhs (raytracer.f95:282-314) given the densities at the 7 stencil points: 7 dipole-field
 // evaluations, 3 + 6 Stix evaluations, 14 dispersion-function evaluations.  Also returns dF/dk and dF/dw
 // at the centre (the group-velocity terms of raytracer.f95:916-919 are the same numbers).
-template <int NP, class CM>
+// SPREAD (dipole field only): the six offset evaluations go through offset_F -- one after the other in the ray's lane, or, when
+// __ballot(need) has at most 8 lanes, point i of the r-th such lane in lane 8 r + i (inputs and results through LDS).
+template <int NP, bool SPREAD = false, class CM>
 __device__ __forceinline__ void rhs_from_plasma(const CM &cm, const double x[3], const double k[3], double w,
                                                 const double d[3], const double (&p)[NP][3],
                                                 const double (&Ns)[NP][4], double rhs[6], double dk[3], double &dw,
-                                                double B[3], const double (*Bpre)[3] = nullptr) {
+                                                double B[3], const double (*Bpre)[3] = nullptr, bool need = true) {
   // use_igrf (wave-uniform): the seven fields are synthesised together (srt_device.hpp igrf_core); dipole: one by one
   const bool igrf = field_is_igrf(cm);
   double Ball[7][3];
@@ -111,8 +136,59 @@ __device__ __forceinline__ void rhs_from_plasma(const CM &cm, const double x[3],
   dw = dFdw(cm.sp, k, w, cm.C, Ns[0], B, B2, Bmag);
   double n[3] = {k[0] * cw, k[1] * cw, k[2] * cw};
   double dx[3];
+  bool spread_done = false;
+  if constexpr (SPREAD) {
+    if (!igrf) { // wave-uniform
+      double F6[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+      const unsigned long long needy = __ballot(need);
+      const int nneedy = __popcll(needy);
+      if (nneedy >= 1 && nneedy <= 8) { // wave-uniform: tail mode
+        __shared__ __attribute__((aligned(16))) double xch[8][48]; // per ray: 6 x {p(3), Ns(4)}, w, n(3)
+        __shared__ __attribute__((aligned(16))) double xchF[8][8];
+        const int lane = (int)__lane_id();
+        const int rank = __popcll(needy & ((1ull << lane) - 1ull));
+        if (need) {
+#pragma unroll
+          for (int i = 1; i <= 6; ++i) {
+            double *q = &xch[rank][7 * (i - 1)];
+            q[0] = p[i][0], q[1] = p[i][1], q[2] = p[i][2];
+            q[3] = Ns[i][0], q[4] = Ns[i][1], q[5] = Ns[i][2], q[6] = Ns[i][3];
+          }
+          xch[rank][42] = w, xch[rank][43] = n[0], xch[rank][44] = n[1], xch[rank][45] = n[2];
+        }
+        __syncthreads(); // block == one wave
+        const int slot = lane >> 3, i = lane & 7;
+        const bool work = slot < nneedy && i >= 1 && i <= 6;
+        const double *src = xch[work ? slot : 0]; // (idle lanes ride along on the first ray's first point: one call site, uniform control flow)
+        const double *q = src + 7 * ((work ? i : 1) - 1);
+        const double F = offset_F(cm, q[0], q[1], q[2], q[3], q[4], q[5], q[6], src[42], src[43], src[44], src[45]);
+        if (work) xchF[slot][i] = F;
+        __syncthreads();
+#pragma unroll
+        for (int i2 = 1; i2 <= 6; ++i2) F6[i2] = xchF[need ? rank : 0][i2];
+        __syncthreads(); // (the next right-hand side overwrites both arrays)
+      } else {
+#pragma unroll 1
+        for (int i = 1; i <= 6; ++i) {
+          double px = p[1][0], py = p[1][1], pz = p[1][2], a0 = Ns[1][0], a1 = Ns[1][1], a2 = Ns[1][2], a3 = Ns[1][3];
+#pragma unroll
+          for (int t = 2; t <= 6; ++t) { // (static indices: the arrays stay in registers)
+            px = i == t ? p[t][0] : px, py = i == t ? p[t][1] : py, pz = i == t ? p[t][2] : pz;
+            a0 = i == t ? Ns[t][0] : a0, a1 = i == t ? Ns[t][1] : a1, a2 = i == t ? Ns[t][2] : a2, a3 = i == t ? Ns[t][3] : a3;
+          }
+          const double F = offset_F(cm, px, py, pz, a0, a1, a2, a3, w, n[0], n[1], n[2]);
+#pragma unroll
+          for (int t = 1; t <= 6; ++t) F6[t] = i == t ? F : F6[t];
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) dx[c] = fdiv(F6[1 + 2 * c] - F6[2 + 2 * c], d[c]) * 0.5;
+      spread_done = true;
+    }
+  }
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
+    if (spread_done) break;
     double Fpm[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -146,7 +222,7 @@ __device__ __forceinline__ void evalrhs(const M &m, const CM &cm, const double x
   stencil_points<7>(x, del, p, d);
   m.template density_stencil<0>(x, d, nullptr, Ns, lds, need);
   SRT_TT(0);
-  rhs_from_plasma<7>(cm, x, x + 3, w, d, p, Ns, rhs, dk, dw, B);
+  rhs_from_plasma<7, spread_rhs<M>()>(cm, x, x + 3, w, d, p, Ns, rhs, dk, dw, B, nullptr, need);
   SRT_TT(1);
 }
 
@@ -483,7 +559,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WaveBudget<M
     // first-stage right-hand side at the would-be new state (also yields its group-velocity terms)
     double rn[6], dk[3], dw, Bn[3];
     SRT_TT(4);
-    rhs_from_plasma<NPOST>(cm, est2, knew, w, dpost, pp, NP_, rn, dk, dw, Bn, IGRF ? Bpost : nullptr);
+    rhs_from_plasma<NPOST, spread_rhs<M>()>(cm, est2, knew, w, dpost, pp, NP_, rn, dk, dw, Bn, IGRF ? Bpost : nullptr, active || needinit);
     SRT_TT(5);
     if (needinit) {
       // launch state and row 0 (:693-742)
