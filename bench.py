@@ -43,6 +43,9 @@ import time
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+# (RCCL between processes shares device memory through dmabuf handles on this driver stack; the legacy IPC mode fails with
+# hipIpcGetMemHandle: invalid argument.  The pool exports this already; set here for launches that do not inherit it.)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
