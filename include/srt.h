@@ -73,7 +73,7 @@ typedef struct srt_params {
                                    that the lanes of a wave start in neighbouring cells of the interp grid and share
                                    coefficient lines (SURVEY.md 8d allows this input permutation; other models ignore it);
                                    2 = as 1 with the rays that are likely to stop early (above 6 kHz, launched inwards)
-                                   behind all others -- an experiment switch for the launch's tail, not a gain */
+                                   behind all others -- an experiment switch for the launch's tail, not a gain (HISTORY.md section 9) */
 } srt_params;
 
 typedef struct srt_model srt_model; /* opaque; owns device copies of all model data */

@@ -1316,7 +1316,7 @@ __device__ __forceinline__ unsigned spread3(unsigned v) { // 0b abc -> 0b a00b00
   v = (v | (v << 2)) & 0x09249249u;
   return v;
 }
-// two_class (ray_order = 2, an experiment switch: DESIGN section 9): rays that are likely to stop early -- above 6 kHz and
+// two_class (ray_order = 2, an experiment switch: HISTORY.md section 9): rays that are likely to stop early -- above 6 kHz and
 // launched inwards: 8.5 % of the BASELINE launch set, mean 75 rows against 197 -- sort behind all others (key bit 30: above the Morton code, 10 bits per axis = bits 0..29)
 __global__ void ray_keys_kernel(const InterpModel *mp, const double *pos0 /* SoA [3][n] */, const double *dir0, const double *w0,
                                 int two_class, long long n, unsigned *keys, int *ids) {

@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/scratch/clock_probe.sh -- the shader clock and power the GPU reports (rocm-smi) while a workload's launch is running:
-# evidence for which kernels are power-bound
+# evidence for which kernels are power-bound (HISTORY.md section 2.5)
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 for spec in "scattered825k 300000" "interp256 1000000" "ngo100k 1000000"; do
   set -- $spec
