@@ -132,3 +132,19 @@ def test_pipelined_gather_world2_gloo():
         p.join(120)
         assert p.exitcode == 0
     assert q.get(timeout=10) is True
+
+
+def test_gather_world8_gloo():
+    """The shape the driver's N = 8 run takes: eight ranks, a launch set that does not divide (shards of 13 and 12 rays), and
+    fewer rays than ranks (five ranks with empty shards send nothing and still take part in the counts exchange)."""
+    for nrays in (101, 3):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker, args=(r, 8, port, nrays, q)) for r in range(8)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(180)
+            assert p.exitcode == 0
+        assert q.get(timeout=10) is True
