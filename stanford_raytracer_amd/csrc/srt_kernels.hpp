@@ -95,8 +95,22 @@ __device__ __noinline__ double offset_F(const CM &cm, double px, double py, doub
 #ifndef SRT_NGO_SPREAD
 #define SRT_NGO_SPREAD 1 // (0: every right-hand side in the ray's own lane, for A/B)
 #endif
+#ifndef SRT_INTERP_SPREAD
+#define SRT_INTERP_SPREAD 0 // (1: the same for the interp model's tail -- measured, HISTORY section 12.3)
+#endif
 template <class M>
-constexpr bool spread_rhs() { return SRT_NGO_SPREAD != 0 && std::is_same<M, NgoModel>::value; }
+constexpr bool spread_rhs() {
+  return (SRT_NGO_SPREAD != 0 && std::is_same<M, NgoModel>::value) || (SRT_INTERP_SPREAD != 0 && std::is_same<M, InterpModel>::value);
+}
+// the exchange area of the spread right-hand sides: ONE allocation per kernel, whichever call sites use it
+struct SpreadLds {
+  double xch[8][48]; // per ray: 6 x {p(3), Ns(4)}, w, n(3)
+  double xchF[8][8];
+};
+__device__ __forceinline__ SpreadLds &spread_lds() {
+  __shared__ __attribute__((aligned(16))) SpreadLds area;
+  return area;
+}
 
 // raytracer_evalrhs (raytracer.f95:282-314) given the densities at the 7 stencil points: 7 dipole-field
 // evaluations, 3 + 6 Stix evaluations, 14 dispersion-function evaluations.  Also returns dF/dk and dF/dw
@@ -143,8 +157,9 @@ __device__ __forceinline__ void rhs_from_plasma(const CM &cm, const double x[3],
       const unsigned long long needy = __ballot(need);
       const int nneedy = __popcll(needy);
       if (nneedy >= 1 && nneedy <= 8) { // wave-uniform: tail mode
-        __shared__ __attribute__((aligned(16))) double xch[8][48]; // per ray: 6 x {p(3), Ns(4)}, w, n(3)
-        __shared__ __attribute__((aligned(16))) double xchF[8][8];
+        SpreadLds &sl_ = spread_lds();
+        double (&xch)[8][48] = sl_.xch;
+        double (&xchF)[8][8] = sl_.xchF;
         const int lane = (int)__lane_id();
         const int rank = __popcll(needy & ((1ull << lane) - 1ull));
         if (need) {
