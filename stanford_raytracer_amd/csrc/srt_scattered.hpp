@@ -554,6 +554,12 @@ struct ScatteredModel {
   static constexpr int LDS_SCRATCH_SLOT = LIST_DOUBLES, LDS_BLOCK_SLOT = LDS_SCRATCH_SLOT + 1, LDS_PARK = LDS_SCRATCH_SLOT + 2,
                        LDS_PHASE = LDS_PARK + 32, LDS_HDR = LDS_SCRATCH_SLOT + 64;
   static constexpr int LDS_DOUBLES = LDS_HDR + 4 * 64;
+#ifndef SRT_SCAT_TAYLOR
+// 1 (round 4): the seven windows of a sample in pass 1 as a cubic in the angle difference about the centre's window (instead of cos / sin
+// series of the difference and the addition theorem), and -- for a stencil all of whose samples are far enough -- the seven weights
+// from a second-order expansion of the weight about the centre (sf_weights); 0: round 3's series everywhere.
+#define SRT_SCAT_TAYLOR 1
+#endif
 #ifndef SRT_SCAT_FUSED
 // 1: the weights and the pair loop of the shared path run FUSED, tile by tile (sf_fused): the 64 records of a tile --
 // {x, y, z, ln N_s, the eight half-weights} -- exist only in LDS, between the lanes that weigh them (lane = sample) and the
@@ -825,6 +831,7 @@ struct ScatteredModel {
   struct Pass1Out {
     double hin8[8];
     int cnt8[8];
+    double rmin; // the list's smallest distance from the centre (sf_weights' choice of tier)
   };
   __device__ __forceinline__ static SRT_LDS Pass1Out *pass1_out(SRT_LDS const int *list) {
     return (SRT_LDS Pass1Out *)((SRT_LDS double *)const_cast<SRT_LDS int *>(list) + LDS_PARK);
@@ -902,6 +909,7 @@ struct ScatteredModel {
     const double mda3[3] = {pg[2][0] - pg[0][0], pg[4][1] - pg[0][1], pg[6][2] - pg[0][2]};
     const double o7[3] = {pg[7][0] - pg[0][0], pg[7][1] - pg[0][1], pg[7][2] - pg[0][2]};
     const double o7sq = o7[0] * o7[0] + o7[1] * o7[1] + o7[2] * o7[2];
+    double rmin_l = 1.0e300; // (this lane's samples)
     // (one sample ahead: the next gather is in flight while this sample is worked on)
     d2_t na = {0.0, 0.0}, nb = na, nc = na, nd = na;
     if (lane < n_list) {
@@ -922,6 +930,7 @@ struct ScatteredModel {
       {
         const double ss = ssc;
         rc = fm::sqrt_pos(ss);
+        rmin_l = fmin(rmin_l, rc);
         fm::sincos_0pi(rc * pi_R, sa, ca);
         const bool in = lv8[0] && ss < r2;
         const double cw = in ? 0.5 + 0.5 * ca : 0.0;
@@ -954,9 +963,13 @@ struct ScatteredModel {
           }
         }
         SF_ROW(eps, t[j] * inv2);
-        SF_ROW(pl, fma(eps[j], 0.0546875, -0.078125));
-        SF_ROW(pl, fma(eps[j], pl[j], 0.125));
-        SF_ROW(pl, fma(eps[j], pl[j], -0.25));
+        if constexpr (SRT_SCAT_TAYLOR != 0) { // (to eps^2: the next term, 5 eps^3 / 64 <= 6e-10 of an angle difference <= 3e-3)
+          SF_ROW(pl, fma(eps[j], 0.125, -0.25));
+        } else {
+          SF_ROW(pl, fma(eps[j], 0.0546875, -0.078125));
+          SF_ROW(pl, fma(eps[j], pl[j], 0.125));
+          SF_ROW(pl, fma(eps[j], pl[j], -0.25));
+        }
         SF_ROW(pl, fma(eps[j], pl[j], 1.0));
         SF_ROW(da, t[j] * hinv);
         SF_ROW(da, da[j] * pl[j]);
@@ -969,6 +982,15 @@ struct ScatteredModel {
             da[j] = (fm::sqrt_pos(tin[j]) - rc) * pi_R;
           }
         }
+        if constexpr (SRT_SCAT_TAYLOR != 0) {
+          // the window W(a) = 1/2 + cos(a)/2 at a_c + da as a cubic in da about a_c: derivatives -sin/2, -cos/2, +sin/2;
+          // |da| <= pi 1e-3 (the free point; 1e-5 for the six offset points): remainder da^4 / 48 <= 2e-12 (1e-21) --
+          // 3 rows instead of 9
+          const double w1 = -0.5 * sa, w2 = -0.25 * ca, w3 = (1.0 / 12.0) * sa, w0c = 0.5 + 0.5 * ca;
+          SF_ROW(h, fma(w3, da[j], w2));
+          SF_ROW(h, fma(h[j], da[j], w1));
+          SF_ROW(h, fma(h[j], da[j], w0c));
+        } else {
         SF_ROW(y, da[j] * da[j]);
         SF_ROW(h, fma(y[j], 1.0 / 24.0, -0.5));
         SF_ROW(r, fma(y[j], 1.0 / 120.0, -1.0 / 6.0));
@@ -978,6 +1000,7 @@ struct ScatteredModel {
         SF_ROW(r, sa * r[j]);
         SF_ROW(h, fma(ca, h[j], -r[j]));
         SF_ROW(h, fma(0.5, h[j], 0.5));
+        }
 #undef SF_ROW
 #pragma unroll
         for (int j = 0; j < NQ; ++j) {
@@ -1047,9 +1070,12 @@ struct ScatteredModel {
       n8[gg] = two & 0xFFFF, n8[gg + 1] = (int)((unsigned)two >> 16);
     }
     if (lane < 8) o->hin8[rev3] = hmine;
+    // (smallest distance = 1 / the largest reciprocal; lanes without a sample hold 1e300; the wave maximum is wave-uniform)
+    const double rmin_w = fdiv(1.0, wave_max_nonneg(fdiv(1.0, rmin_l)));
     if (lane == 0) {
 #pragma unroll
       for (int gg = 0; gg < 8; ++gg) o->cnt8[gg] = n8[gg];
+      o->rmin = rmin_w;
     }
     __syncthreads(); // block == one wave: the records and the sums written above are read by other lanes next
     SRT_PHASE(2);
@@ -1094,6 +1120,89 @@ struct ScatteredModel {
     const double o7[3] = {pg[7][0] - pg[0][0], pg[7][1] - pg[0][1], pg[7][2] - pg[0][2]};
     const double o7sq = o7[0] * o7[0] + o7[1] * o7[1] + o7[2] * o7[2];
     const Side side = side_of(list, n_list);
+    // ---- second-order tier (round 4, SRT_SCAT_TAYLOR).  The weight of a sample at a point is expanded about the centre in
+    // dr = r_g - r_c and dh = h_g - h_c:  w + dr (w_r + w_rh dh + (w_rr / 2) dr) + w_h dh, with (E = exp(-u), u = x**1.1, W the window)
+    //   w = E W / 2,  w_r = E (L W + W') / 2,  w_rr = E ((L' + L^2) W + 2 L W' + W'') / 2,  L = -1.1 u / r,  L' = -0.11 u / r^2,
+    //   w_h = w 1.1 u / h,  w_rh = w_r 1.1 u / h + w 1.21 u / (h r).
+    // Remainder (L dr)^3 / 6 with |L dr| <= 1.1 (u / r) d, and u / r grows like r^0.1: largest at the search radius, whatever the
+    // sample.  Taken for a stencil (one decision, wave-uniform) when 1.1 u(R) d / R <= 2e-4 (remainder <= 2e-12 of a weight),
+    // 1.1 u(R) |h_c / h_g - 1| <= 1e-5 (the neglected dh^2 term: <= 6e-11) and every sample is at least 1e3 stencil widths away
+    // (pass 1's smallest distance: the dr series' own condition) -- tools/scattered_taylor_prototype.py: ln N at the seven points
+    // to 4e-13, its central-difference gradient to 3e-8 median against the exact weights.  11 rows per point instead of 34;
+    // every other stencil takes the series below, as in round 3.
+    bool tay_all = false;
+    double tc1 = 0.0, tc2 = 0.0, ihc = 0.0;
+    double dh8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if constexpr (SRT_SCAT_TAYLOR != 0) {
+      const double rmin = uni(o->rmin);
+      if (base_ok && rmin > 0.0) {
+        const double irm = fdiv(1.0, rmin + reps), iR = fdiv(1.0, radius);
+        const double umax = 1.1 * (radius + reps) * fm::exp_any(0.1 * fm::log_pos(radius + reps)) * sh; // 1.1 u at the radius
+        tay_all = dmax6 * irm <= 1.0e-3 && umax * (dmax6 * iR) <= 2.0e-4 && umax * etamax6 <= 1.0e-5 &&
+                  (!fit8[7] || (p7near && d7 * irm <= 1.0e-3 && umax * (d7 * iR) <= 2.0e-4 && umax * eta7 <= 1.0e-5));
+      }
+      tc1 = -0.5 * pi_R, tc2 = -0.5 * pi_R * pi_R;
+      ihc = tay_all ? fdiv(1.0, hin8[0]) : 0.0;
+#pragma unroll
+      for (int gg = 0; gg < 8; ++gg) dh8[gg] = hin8[gg] - hin8[0];
+    }
+    auto weigh_taylor = [&](int k, const d2_t s0, const d2_t s1, const d2_t s2) {
+      const double q0 = s0.x, q1 = s0.y, q2 = s1.x, rc = s1.y, ca = s2.x, sa = s2.y;
+      const double dc[3] = {q0 - pg[0][0], q1 - pg[0][1], q2 - pg[0][2]};
+      const double ssc = dc[0] * dc[0] + dc[1] * dc[1] + dc[2] * dc[2];
+      const double xr = rc + reps;
+      const double a11 = xr * fm::exp_any(0.1 * fm::log_pos(xr));
+      const double inv = fdiv(1.0, xr), inv2 = inv * inv, hinv = 0.5 * inv;
+      const double u = a11 * sh;
+      const double Eh = 0.5 * fm::exp_any(-u), thr = 0.5 * 1.0e-16;
+      const double f0 = 0.5 + 0.5 * ca, fp = tc1 * sa, fpp = tc2 * ca;
+      const double w0 = Eh * f0;
+      const double L1 = -1.1 * u * inv, L2h = -0.055 * u * inv2;
+      const double wr = Eh * fma(L1, f0, fp);
+      const double hrr = Eh * fma(fma(0.5 * L1, L1, L2h), f0, fma(L1, fp, 0.5 * fpp));
+      const double kh = 1.1 * u * ihc;
+      const double wh = w0 * kh, wrh = fma(wr, kh, w0 * (1.1 * kh * inv));
+      double w8[8];
+      w8[0] = (fit8[0] && ssc < r2 && (w0 > thr || !usemask)) ? w0 : 0.0;
+      w8[7] = 0.0;
+      auto chains = [&](auto nq) {
+        constexpr int NQ = decltype(nq)::value;
+#define SF_ROW(dst, expr)                                                                                              \
+  _Pragma("unroll") for (int j = 0; j < NQ; ++j) dst[j] = expr;                                                        \
+  _Pragma("unroll") for (int j = 0; j < NQ; ++j) asm volatile("" : "+v"(dst[j]))
+        double t[NQ], tin[NQ], au[NQ], dr[NQ], X[NQ];
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+          if (j < 6) {
+            const double dl = (j & 1) ? mda3[j >> 1] : da3[j >> 1];
+            const double x = fma(-2.0, dc[j >> 1], dl);
+            t[j] = dl * x;
+            tin[j] = fma(dl, x, ssc);
+          } else {
+            t[j] = o7sq - 2.0 * (o7[0] * dc[0] + o7[1] * dc[1] + o7[2] * dc[2]);
+            tin[j] = ssc + t[j];
+          }
+        }
+        SF_ROW(au, t[j] * inv2); // eps; dr = (t / 2r)(1 - eps/4 + eps^2/8): the next term, 5 eps^3 / 64 <= 6e-10, times |L dr| <= 2e-4
+        SF_ROW(X, fma(au[j], 0.125, -0.25));
+        SF_ROW(X, fma(au[j], X[j], 1.0));
+        SF_ROW(dr, t[j] * hinv);
+        SF_ROW(dr, dr[j] * X[j]);
+        SF_ROW(au, fma(wrh, dh8[j + 1], wr));
+        SF_ROW(au, fma(hrr, dr[j], au[j]));
+        SF_ROW(X, fma(wh, dh8[j + 1], w0));
+        SF_ROW(X, fma(dr[j], au[j], X[j]));
+#undef SF_ROW
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) w8[j + 1] = (fit8[j + 1] && tin[j] < r2 && (X[j] > thr || !usemask)) ? X[j] : 0.0;
+      };
+      if (fit8[7]) chains(std::integral_constant<int, 7>{}); // (wave-uniform)
+      else chains(std::integral_constant<int, 6>{});
+      *chunk(rec, 4, k) = d2_t{w8[0], w8[1]};
+      *chunk(rec, 5, k) = d2_t{w8[2], w8[3]};
+      *chunk(rec, 6, k) = d2_t{w8[4], w8[5]};
+      *chunk(rec, 7, k) = d2_t{w8[6], w8[7]};
+    };
     auto weigh = [&](int k, const d2_t s0, const d2_t s1, const d2_t s2) {
       const double q0 = s0.x, q1 = s0.y, q2 = s1.x, rc = s1.y, ca = s2.x, sa = s2.y;
       const double dc[3] = {q0 - pg[0][0], q1 - pg[0][1], q2 - pg[0][2]};
@@ -1203,6 +1312,15 @@ struct ScatteredModel {
     // the samples whose {x, y, z, r_c, cos, sin} wait in LDS: no load from device memory in this loop, so nothing in it ever
     // waits for the previous trip's stores
     const int nlds = n_list < side.cap ? n_list : side.cap;
+    if (tay_all) { // (wave-uniform)
+#pragma unroll 1
+      for (int k = lane; k < nlds; k += 64) weigh_taylor(k, side.a[k], side.b[k], side.c[k]);
+#pragma unroll 1
+      for (int k = nlds + lane; k < n_list; k += 64) {
+        const d2_t c0 = *chunk(rec, 0, k), c1 = *chunk(rec, 1, k), c4 = *chunk(rec, 4, k), c5 = *chunk(rec, 5, k);
+        weigh_taylor(k, c0, d2_t{c1.x, c4.x}, c5);
+      }
+    } else {
 #pragma unroll 1
     for (int k = lane; k < nlds; k += 64) weigh(k, side.a[k], side.b[k], side.c[k]);
     // a list longer than the side arrays: the rest back from their records
@@ -1210,6 +1328,7 @@ struct ScatteredModel {
     for (int k = nlds + lane; k < n_list; k += 64) {
       const d2_t c0 = *chunk(rec, 0, k), c1 = *chunk(rec, 1, k), c4 = *chunk(rec, 4, k), c5 = *chunk(rec, 5, k);
       weigh(k, c0, d2_t{c1.x, c4.x}, c5);
+    }
     }
     __syncthreads(); // block == one wave: the weights written above are read by other lanes next
     SRT_PHASE(3);
