@@ -832,6 +832,7 @@ struct ScatteredModel {
     double hin8[8];
     int cnt8[8];
     double rmin; // the list's smallest distance from the centre (sf_weights' choice of tier)
+    int kept8[8]; // written by sf_weights: samples that keep a non-zero weight at point g (the mask rule's count, :316-323)
   };
   __device__ __forceinline__ static SRT_LDS Pass1Out *pass1_out(SRT_LDS const int *list) {
     return (SRT_LDS Pass1Out *)((SRT_LDS double *)const_cast<SRT_LDS int *>(list) + LDS_PARK);
@@ -1093,9 +1094,10 @@ struct ScatteredModel {
     const int lane = threadIdx.x, g = lane >> 3;
     const double r2 = radius * radius, pi_R = PI / radius, reps = radius * 5.0e-16;
     SRT_PHASE_BEGIN(list);
-    SRT_LDS const Pass1Out *o = pass1_out(list);
+    SRT_LDS Pass1Out *o = pass1_out(list);
     double hin8[8], pg[8][3];
     bool fit8[8], lv8[8];
+    int kept_c[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // wave-uniform: samples that keep a non-zero weight at point g
 #pragma unroll
     for (int gg = 0; gg < 8; ++gg) {
       hin8[gg] = uni(o->hin8[gg]);
@@ -1202,6 +1204,10 @@ struct ScatteredModel {
       *chunk(rec, 5, k) = d2_t{w8[2], w8[3]};
       *chunk(rec, 6, k) = d2_t{w8[4], w8[5]};
       *chunk(rec, 7, k) = d2_t{w8[6], w8[7]};
+      // (one compare per point and sample here instead of a select, a compare and an add per (point, neighbour) in the pair
+      // loop; the count itself is scalar arithmetic)
+#pragma unroll
+      for (int gg = 0; gg < 8; ++gg) kept_c[gg] += __popcll(__ballot(w8[gg] != 0.0));
     };
     auto weigh = [&](int k, const d2_t s0, const d2_t s1, const d2_t s2) {
       const double q0 = s0.x, q1 = s0.y, q2 = s1.x, rc = s1.y, ca = s2.x, sa = s2.y;
@@ -1308,6 +1314,10 @@ struct ScatteredModel {
       *chunk(rec, 5, k) = d2_t{w8[2], w8[3]};
       *chunk(rec, 6, k) = d2_t{w8[4], w8[5]};
       *chunk(rec, 7, k) = d2_t{w8[6], w8[7]};
+      // (one compare per point and sample here instead of a select, a compare and an add per (point, neighbour) in the pair
+      // loop; the count itself is scalar arithmetic)
+#pragma unroll
+      for (int gg = 0; gg < 8; ++gg) kept_c[gg] += __popcll(__ballot(w8[gg] != 0.0));
     };
     // the samples whose {x, y, z, r_c, cos, sin} wait in LDS: no load from device memory in this loop, so nothing in it ever
     // waits for the previous trip's stores
@@ -1330,6 +1340,19 @@ struct ScatteredModel {
       weigh(k, c0, d2_t{c1.x, c4.x}, c5);
     }
     }
+    // the records behind the list's end, up to the pair loop's last whole 64-record chunk, carry zero weights: the loop tests no index
+#pragma unroll 1
+    for (int k = n_list + lane; k < ((n_list + 63) & ~63); k += 64) {
+      const d2_t z = {0.0, 0.0};
+      *chunk(rec, 4, k) = z;
+      *chunk(rec, 5, k) = z;
+      *chunk(rec, 6, k) = z;
+      *chunk(rec, 7, k) = z;
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int gg = 0; gg < 8; ++gg) o->kept8[gg] = kept_c[gg];
+    }
     __syncthreads(); // block == one wave: the weights written above are read by other lanes next
     SRT_PHASE(3);
   }
@@ -1348,7 +1371,7 @@ struct ScatteredModel {
     double A[(O3 || J == 10) ? 1 : NT], b[O3 ? 1 : J][4];
     double Mm[J == 10 ? Moments::N : 1]; // order 2: the 35 moments stand in for the 55 entries of A while summing
     typename std::conditional<O3, Sums20, int>::type S20;
-    int kept = 0;
+    kept_out = pass1_out(list)->kept8[g]; // (counted where the weights were made; the park area is outside the ring)
     if constexpr (O3) S20.zero();
 #pragma unroll
     for (int t = 0; t < ((O3 || J == 10) ? 1 : NT); ++t) A[t] = 0.0;
@@ -1401,12 +1424,12 @@ struct ScatteredModel {
       const int nchunk = (n_list + 63) >> 6; // wave-uniform
       SRT_AS3 char *const ring = (SRT_AS3 char *)list;
       auto issue = [&](int c) {
-        int r = c * 64 + lane;
-        r = r < n_list ? r : n_list - 1;
+        const int r = c * 64 + lane;
+        const int rc = r < n_list ? r : n_list - 1; // (x, y, z, ln N of the last sample behind the end: finite; the weights there are zero)
         SRT_AS3 char *dst = ring + (c % NBUF) * 8192;
 #pragma unroll
         for (int t = 0; t < 8; ++t) // (chunk-major staging: instruction t reads 1 KiB of consecutive bytes)
-          __builtin_amdgcn_global_load_lds((const SRT_AS1 void *)chunk(rec, t, r), (SRT_AS3 void *)(dst + 1024 * t), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((const SRT_AS1 void *)chunk(rec, t, t < 4 ? rc : r), (SRT_AS3 void *)(dst + 1024 * t), 16, 0, 0);
       };
       const bool any = __any(fit);
       if (any) {
@@ -1445,12 +1468,9 @@ struct ScatteredModel {
           auto landed = [&](RecRegs &R) {
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(R.c0), "+v"(R.c1), "+v"(R.c2), "+v"(R.ln3), "+v"(R.w2) : : "memory");
           };
-          auto use = [&](const RecRegs &R, int i) {
-            const int k = c * 64 + 8 * i + sub;
-            const double w2 = k < n_list ? R.w2 : 0.0;
-            kept += w2 != 0.0 ? 1 : 0;
+          auto use = [&](const RecRegs &R, int) {
             const double ln[4] = {R.c1.y, R.c2.x, R.c2.y, R.ln3};
-            fold(w2, R.c0.x - p[0], R.c0.y - p[1], R.c1.x - p[2], ln);
+            fold(R.w2, R.c0.x - p[0], R.c0.y - p[1], R.c1.x - p[2], ln);
           };
           RecRegs Ra, Rb;
           rd(Ra, 0);
@@ -1468,7 +1488,6 @@ struct ScatteredModel {
       }
       InterpModel::wait_vm<0>();
     }
-    kept_out = group_sum(kept);
     SRT_PHASE(4);
     // combine the 8 lanes' partial sums and solve
     fi.v[0] = fi.v[1] = fi.v[2] = fi.v[3] = 0.0;
