@@ -1126,9 +1126,12 @@ struct ScatteredModel {
     // dr = r_g - r_c and dh = h_g - h_c:  w + dr (w_r + w_rh dh + (w_rr / 2) dr) + w_h dh, with (E = exp(-u), u = x**1.1, W the window)
     //   w = E W / 2,  w_r = E (L W + W') / 2,  w_rr = E ((L' + L^2) W + 2 L W' + W'') / 2,  L = -1.1 u / r,  L' = -0.11 u / r^2,
     //   w_h = w 1.1 u / h,  w_rh = w_r 1.1 u / h + w 1.21 u / (h r).
+    // (and (w_hh / 2) dh^2, w_hh = w ((1.1 u / h)^2 - 2.31 u / h^2)).
     // Remainder (L dr)^3 / 6 with |L dr| <= 1.1 (u / r) d, and u / r grows like r^0.1: largest at the search radius, whatever the
     // sample.  Taken for a stencil (one decision, wave-uniform) when 1.1 u(R) d / R <= 2e-4 (remainder <= 2e-12 of a weight),
-    // 1.1 u(R) |h_c / h_g - 1| <= 1e-5 (the neglected dh^2 term: <= 6e-11) and every sample is at least 1e3 stencil widths away
+    // 1.1 u(R) |h_c / h_g - 1| <= 2e-4 (its cube / 6: 1e-12) and every sample is at least 100 stencil widths away (eps <= 2e-2:
+    // the dr series to eps^3 leaves 7 eps^4 / 128 <= 1e-8 of dr, times |L dr|; a near sample's u is small: 1.1 u d / r stays under
+    // the bound at the radius)
     // (pass 1's smallest distance: the dr series' own condition) -- tools/scattered_taylor_prototype.py: ln N at the seven points
     // to 4e-13, its central-difference gradient to 3e-8 median against the exact weights.  11 rows per point instead of 34;
     // every other stencil takes the series below, as in round 3.
@@ -1140,8 +1143,8 @@ struct ScatteredModel {
       if (base_ok && rmin > 0.0) {
         const double irm = fdiv(1.0, rmin + reps), iR = fdiv(1.0, radius);
         const double umax = 1.1 * (radius + reps) * fm::exp_any(0.1 * fm::log_pos(radius + reps)) * sh; // 1.1 u at the radius
-        tay_all = dmax6 * irm <= 1.0e-3 && umax * (dmax6 * iR) <= 2.0e-4 && umax * etamax6 <= 1.0e-5 &&
-                  (!fit8[7] || (p7near && d7 * irm <= 1.0e-3 && umax * (d7 * iR) <= 2.0e-4 && umax * eta7 <= 1.0e-5));
+        tay_all = dmax6 * irm <= 1.0e-2 && umax * (dmax6 * iR) <= 2.0e-4 && umax * etamax6 <= 2.0e-4 &&
+                  (!fit8[7] || (p7near && d7 * irm <= 1.0e-2 && umax * (d7 * iR) <= 2.0e-4 && umax * eta7 <= 2.0e-4));
       }
       tc1 = -0.5 * pi_R, tc2 = -0.5 * pi_R * pi_R;
       ihc = tay_all ? fdiv(1.0, hin8[0]) : 0.0;
@@ -1164,6 +1167,7 @@ struct ScatteredModel {
       const double hrr = Eh * fma(fma(0.5 * L1, L1, L2h), f0, fma(L1, fp, 0.5 * fpp));
       const double kh = 1.1 * u * ihc;
       const double wh = w0 * kh, wrh = fma(wr, kh, w0 * (1.1 * kh * inv));
+      const double hhh = 0.5 * w0 * fma(kh, kh, -2.31 * u * (ihc * ihc)); // w_hh / 2
       double w8[8];
       w8[0] = (fit8[0] && ssc < r2 && (w0 > thr || !usemask)) ? w0 : 0.0;
       w8[7] = 0.0;
@@ -1185,14 +1189,16 @@ struct ScatteredModel {
             tin[j] = ssc + t[j];
           }
         }
-        SF_ROW(au, t[j] * inv2); // eps; dr = (t / 2r)(1 - eps/4 + eps^2/8): the next term, 5 eps^3 / 64 <= 6e-10, times |L dr| <= 2e-4
-        SF_ROW(X, fma(au[j], 0.125, -0.25));
+        SF_ROW(au, t[j] * inv2); // eps; dr = (t / 2r)(1 - eps/4 + eps^2/8 - 5 eps^3/64)
+        SF_ROW(X, fma(au[j], -0.078125, 0.125));
+        SF_ROW(X, fma(au[j], X[j], -0.25));
         SF_ROW(X, fma(au[j], X[j], 1.0));
         SF_ROW(dr, t[j] * hinv);
         SF_ROW(dr, dr[j] * X[j]);
         SF_ROW(au, fma(wrh, dh8[j + 1], wr));
         SF_ROW(au, fma(hrr, dr[j], au[j]));
-        SF_ROW(X, fma(wh, dh8[j + 1], w0));
+        SF_ROW(X, fma(hhh, dh8[j + 1], wh));
+        SF_ROW(X, fma(X[j], dh8[j + 1], w0));
         SF_ROW(X, fma(dr[j], au[j], X[j]));
 #undef SF_ROW
 #pragma unroll
