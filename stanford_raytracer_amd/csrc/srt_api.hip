@@ -1520,6 +1520,15 @@ extern "C" int srt_trace_batch_device(srt_model *m, const srt_params *p, int64_t
     fprintf(stderr, "\n");
     memset(h, 0, sizeof h);
     HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(srt_phase_cycles), h, sizeof h));
+    {
+      unsigned long long ts[8];
+      HIP_OK(hipMemcpyFromSymbol(ts, HIP_SYMBOL(srt_tier_stats), sizeof ts));
+      fprintf(stderr, "srt tier stats (stencils, second-order, no centre, near sample, L bound, h bound, free point, other):");
+      for (int i = 0; i < 8; ++i) fprintf(stderr, " %llu", ts[i]);
+      fprintf(stderr, "\n");
+      memset(ts, 0, sizeof ts);
+      HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(srt_tier_stats), ts, sizeof ts));
+    }
     unsigned long long ws[4];
     float ms = 0.f;
     HIP_OK(hipMemcpyFromSymbol(ws, HIP_SYMBOL(srt_wave_stats), sizeof ws));
