@@ -577,6 +577,11 @@ struct ScatteredModel {
   static constexpr int BLOCK_CAP = 4096, BLOCK_DOUBLES = 64 * BLOCK_CAP * 2;
   static constexpr int TRIP_MAX = 9 * 64; // entries one trip of a 27-cell scan can add
 
+  // block == one wave, and the LDS accesses of a wave complete in issue order: ordering LDS writes before other lanes' reads
+  // needs no s_barrier and -- unlike __syncthreads(), which waits for vmcnt(0) too -- no wait for the global / scratch stores in
+  // flight (the owner's 32 results on their way to scratch at every hand-off: 8 k cycles of a stencil's 95 k sat there); only the
+  // compiler must not move LDS accesses across.  NOT for LDS-DMA landings or for global data handed between lanes.
+  __device__ __forceinline__ static void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
   template <int CTRL>
   __device__ __forceinline__ static double dpp_move(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -1081,7 +1086,10 @@ struct ScatteredModel {
       for (int gg = 0; gg < 8; ++gg) o->cnt8[gg] = n8[gg];
       o->rmin = rmin_w;
     }
-    __syncthreads(); // block == one wave: the records and the sums written above are read by other lanes next
+    // (block == one wave) the sums and the side arrays written above are read by other lanes next: LDS only -- unless the list is
+    // longer than the side arrays, whose rest the weights pass reads back from the records (global memory: the stores must have landed)
+    if (n_list > (FUSED ? side2.cap : side.cap)) __syncthreads();
+    else wave_lds_sync();
     SRT_PHASE(2);
   }
 
@@ -1541,12 +1549,12 @@ struct ScatteredModel {
           }
         };
         pairs(pairs, std::integral_constant<int, 0>{});
-        __syncthreads(); // block == one wave: the totals written above are read by the group's other lanes below
+        wave_lds_sync(); // block == one wave: the totals written above are read by the group's other lanes below
         if (fit) {
           double f1;
           if (solve10_parked(area, sub & 3, f1) == 0) fi.v[0] = fi.v[1] = fi.v[2] = fi.v[3] = f1; // (this lane's species only)
         }
-        __syncthreads(); // (the area is list space again)
+        wave_lds_sync(); // (the area is list space again)
       } else {
 #pragma unroll
         for (int t = 0; t < NT; ++t) A[t] = group_sum(A[t]);
@@ -2339,7 +2347,7 @@ struct ScatteredModel {
         if (B.count >= 0) {
           n_list = M.filter_block(B, pc, radius + ext + slack, blk, lists);
           shared = true;
-          __syncthreads(); // orders the list writes before the reads below
+          wave_lds_sync(); // orders the list writes before the reads below
         }
       }
       if (!shared && geom &&
@@ -2375,7 +2383,7 @@ struct ScatteredModel {
         const double fm_ = sm == 0 ? fi.v[0] : (sm == 1 ? fi.v[1] : (sm == 2 ? fi.v[2] : fi.v[3]));
         const double val = (live && sm < nspec) ? fm::exp_any(fm_) : 0.0; // failed fit: fi = 0 -> Ns = 1
         if ((lane & 7) < 4) ((SRT_LDS double *)park)[4 * g + sm] = val;
-        __syncthreads();
+        wave_lds_sync();
         if (lane == j) {
 #pragma unroll
           for (int gg = 0; gg < 8; ++gg) {
@@ -2389,7 +2397,7 @@ struct ScatteredModel {
           }
         }
       }
-      __syncthreads(); // the lists are reused by the next owner
+      wave_lds_sync(); // the lists are reused by the next owner
       SRT_PHASE(6);
     }
     SRT_PHASE_FLUSH(lists);
