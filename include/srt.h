@@ -100,7 +100,9 @@ int srt_model_create_interp(int nspec, int nx, int ny, int nz, const double boun
                             const double *qs, const double *ms, const double *F,
                             const double *const *derivs, int yearday, int msec, srt_model **out);
 /* modelnum=4: scattered ln(N_s) samples, text file of gcpm_dens_model_buildgrid_random.f95:210-225;
- * parameters are the --scattered_interp_* flags of raytracer_driver.f95:690-728 */
+ * parameters are the --scattered_interp_* flags of raytracer_driver.f95:690-728.  order = degree of the fitted monomials: 0..3 (the
+ * reference's tabular_monomials, lsinterp_mod.f95:70-99) on the kernels built for speed, 4 and 5 (its generate_monomials, :114-164:
+ * 35 / 56 monomials) on one cooperative path that answers at ~1 % of order 2's rate; order >= 6 is refused with SRT_EINVAL */
 int srt_model_create_scattered_file(const char *ptsfile, int yearday, int msec, double window_scale,
                                     int order, int exact, double local_window_scale, srt_model **out);
 /* The same with the reference's kd-tree ROOT reproduced (opt-in, for diffing against a reference binary): the reference's

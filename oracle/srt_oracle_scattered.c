@@ -87,7 +87,25 @@ static void kd_search(struct so_scattered *sc, int t, const double p[3], double 
 }
 
 /* tabular_monomials for 3 dimensions (lsinterp_mod.f95:70-99) */
-static int monomials3(int degree, int ex[20][3]) {
+#define SO_MAXORDER 6
+#define SO_MAXJ 84 /* (6+3 choose 3) */
+/* generate_monomials for 3 dimensions (lsinterp_mod.f95:114-164): every triple of 0..degree, last dimension fastest, kept when its
+ * sum is <= degree -- the same sequence as the tables above for degrees 0..3 */
+static int monomials3_general(int degree, int ex[SO_MAXJ][3]) {
+  int J = 0;
+  for (int a = 0; a <= degree; a++)
+    for (int b = 0; b <= degree; b++)
+      for (int c = 0; c <= degree; c++)
+        if (a + b + c <= degree) {
+          ex[J][0] = a;
+          ex[J][1] = b;
+          ex[J][2] = c;
+          J++;
+        }
+  return J;
+}
+static int monomials3(int degree, int ex[SO_MAXJ][3]) {
+  if (degree > 3) return monomials3_general(degree, ex); /* lsinterp_mod.f95:273-281 */
   static const int e1[3][20] = {{0}, {0}, {0}};
   (void)e1;
   static const int x0[1] = {0}, y0[1] = {0}, z0[1] = {0};
@@ -132,8 +150,9 @@ static double ipow(double b, int e) {
   return r;
 }
 
-/* dposv('U') for n <= 20: dpotf2 + dpotrs (LAPACK 3.2.1 unblocked path), b overwritten by the solution */
-static int dposv_upper(int n, double A[20][20], double b[20]) {
+/* dposv('U') for n <= 84: dpotf2 + dpotrs (LAPACK 3.2.1; dpotrf takes its unblocked path below the block size of 64 -- orders
+ * 0..5; order 6 (n = 84) would run the blocked form there, whose sums are the same in another order), b overwritten by the solution */
+static int dposv_upper(int n, double A[SO_MAXJ][SO_MAXJ], double b[SO_MAXJ]) {
   for (int j = 0; j < n; j++) {
     double s = 0.0;
     for (int l = 0; l < j; l++) s = s + A[l][j] * A[l][j];
@@ -164,7 +183,7 @@ static int dposv_upper(int n, double A[20][20], double b[20]) {
 
 /* lsinterp (lsinterp_mod.f95:244-449), scaled = 0 */
 static int lsinterp(struct so_scattered *sc, const double rin[3], double radius, double fi[4]) {
-  int ex[20][3];
+  int ex[SO_MAXJ][3];
   int J = monomials3(sc->order, ex);
   int I = 0;
   kd_search(sc, sc->root, rin, radius, &I);
@@ -205,7 +224,8 @@ static int lsinterp(struct so_scattered *sc, const double rin[3], double radius,
         if (ex[j][k] != 0) e = e * ipow(q[k] - rin[k], ex[j][k]);
       E[(size_t)j * Ik + i] = dinv[i] * e;
     }
-  double A[20][20], c[20];
+  static __thread double A[SO_MAXJ][SO_MAXJ];
+  double c[SO_MAXJ];
   for (int a = 0; a < J; a++)
     for (int b = 0; b < J; b++) {
       double t = 0.0;
@@ -284,7 +304,7 @@ so_model *so_model_create_scattered_file(const char *ptsfile, int yearday, int m
     return NULL;
   }
   int nspec = (int)hdr[0];
-  if (nspec < 1 || nspec > SO_MAXSPEC || order < 0 || order > 3) {
+  if (nspec < 1 || nspec > SO_MAXSPEC || order < 0 || order > SO_MAXORDER) {
     fclose(f);
     return NULL;
   }

@@ -758,7 +758,7 @@ static int sample_model_on_grid(srt_model *src, int compder, int nx, int ny, int
   else if (src->kind == 3)
     hipLaunchKernelGGL((sample_grid_kernel<InterpModel, true>), dim3(blocks), dim3(WAVE), 0, 0, (const InterpModel *)src->d_model, g, A);
   else
-    hipLaunchKernelGGL((sample_grid_kernel<ScatteredModel, false>), dim3(blocks), dim3(WAVE), 0, 0, (const ScatteredModel *)src->d_model, g, A);
+    hipLaunchKernelGGL((sample_grid_kernel<ScatteredModel, true>), dim3(blocks), dim3(WAVE), 0, 0, (const ScatteredModel *)src->d_model, g, A);
   hipError_t e = hipDeviceSynchronize();
   if (e != hipSuccess) return srt_set_error(SRT_EDEVICE, "grid sampling failed: %s", hipGetErrorString(e));
   return SRT_OK;
@@ -838,9 +838,11 @@ extern "C" int srt_model_create_scattered_file_root(const char *ptsfile, int yea
                                                     srt_model **out) {
   if (!ptsfile || !out) return srt_set_error(SRT_EINVAL, "null argument");
   if (root_sample < -1) return srt_set_error(SRT_EINVAL, "root_sample must be -1 (none) or a 0-based record number");
-  if (order < 0 || order > 3) // tabular_monomials covers degrees 0..3 (lsinterp_mod.f95:76-99); beyond: generate_monomials, not built
-    return srt_set_error(SRT_EINVAL, "scattered_interp_order=%d: orders 0..3 are supported (the reference's generate_monomials orders, "
-                                     "N >= 4, are not built: stay on the Fortran path for them)", order);
+  // orders 0..3: tabular_monomials (lsinterp_mod.f95:76-99), their own kernels; 4 and 5: generate_monomials (:114-164), one
+  // cooperative path built to answer (srt_scattered.hpp gen_point); beyond: 84+ monomials, no room in a wave's LDS
+  if (order < 0 || order > 5)
+    return srt_set_error(SRT_EINVAL, "scattered_interp_order=%d: orders 0..5 are supported (the reference's generate_monomials orders "
+                                     "N >= 6 are not built: stay on the Fortran path for them)", order);
   if (!(window_scale > 0) || !(local_window_scale > 0)) return srt_set_error(SRT_EINVAL, "window scales must be > 0");
   DeviceScope srt_iscope_;
   int rc = srt_iscope_.enter_default();
@@ -965,7 +967,7 @@ extern "C" int srt_plasma_params(srt_model *m, int64_t n, const double *x, doubl
   if (m->kind == 1) launch_wave_blocks(params_kernel<NgoModel, false>, n, 0, (const NgoModel *)m->d_model, (const Common *)m->d_common, (long long)n, (const double *)dx.p, dout.p);
   else if (m->kind == 3) launch_wave_blocks(params_kernel<InterpModel, true>, n, 0, (const InterpModel *)m->d_model, (const Common *)m->d_common, (long long)n, (const double *)dx.p, dout.p);
   else if (m->kind == 4)
-    launch_wave_blocks(params_kernel<ScatteredModel, false>, n, 0, (const ScatteredModel *)m->d_model, (const Common *)m->d_common, (long long)n, (const double *)dx.p, dout.p);
+    launch_wave_blocks(params_kernel<ScatteredModel, true>, n, 0, (const ScatteredModel *)m->d_model, (const Common *)m->d_common, (long long)n, (const double *)dx.p, dout.p);
   else return srt_set_error(SRT_EINVAL, "model kind %d unsupported", m->kind);
   std::vector<double> h(19 * n);
   HIP_OK(hipMemcpy(h.data(), dout.p, h.size() * sizeof(double), hipMemcpyDeviceToHost));
@@ -996,7 +998,7 @@ extern "C" int srt_dispersion(srt_model *m, int64_t n, const double *x, const do
   else if (m->kind == 3)
     launch_wave_blocks(dispersion_kernel<InterpModel, true>, n, 0, (const InterpModel *)m->d_model, (const Common *)m->d_common, (long long)n, (const double *)dx.p, (const double *)dk.p, (const double *)dw.p, dout.p);
   else if (m->kind == 4)
-    launch_wave_blocks(dispersion_kernel<ScatteredModel, false>, n, 0, (const ScatteredModel *)m->d_model, (const Common *)m->d_common, (long long)n, (const double *)dx.p, (const double *)dk.p, (const double *)dw.p, dout.p);
+    launch_wave_blocks(dispersion_kernel<ScatteredModel, true>, n, 0, (const ScatteredModel *)m->d_model, (const Common *)m->d_common, (long long)n, (const double *)dx.p, (const double *)dk.p, (const double *)dw.p, dout.p);
   else return srt_set_error(SRT_EINVAL, "model kind %d unsupported", m->kind);
   HIP_OK(hipMemcpy(out, dout.p, 10 * n * sizeof(double), hipMemcpyDeviceToHost));
   return SRT_OK;
@@ -1099,7 +1101,7 @@ static void smp_eval(srt_model *src, long long n, double *rec) {
   if (n <= 0) return;
   if (src->kind == 1) launch_wave_blocks(smp_eval_kernel<NgoModel, false>, n, 0, (const NgoModel *)src->d_model, n, rec);
   else if (src->kind == 3) launch_wave_blocks(smp_eval_kernel<InterpModel, true>, n, 0, (const InterpModel *)src->d_model, n, rec);
-  else launch_wave_blocks(smp_eval_kernel<ScatteredModel, false>, n, 0, (const ScatteredModel *)src->d_model, n, rec);
+  else launch_wave_blocks(smp_eval_kernel<ScatteredModel, true>, n, 0, (const ScatteredModel *)src->d_model, n, rec);
 }
 
 extern "C" int srt_build_samples(srt_model *src, const srt_sampler_params *sp, int64_t n_in, const double *in_pts,

@@ -2238,6 +2238,282 @@ struct ScatteredModel {
     return n_list;
   }
 
+  // ------------------------------------------------------------------------------------------
+  // Orders >= 4: the reference leaves its tables there and generates the exponent triples (lsinterp_mod.f95:114-164, 273-281);
+  // J = 35 monomials at order 4, 56 at order 5.  Nobody ships an input that asks for them, so this path is built to ANSWER, not
+  // to be fast: the whole wave fits ONE point at a time.  The J (J + 1) / 2 entries of E^T E and the 4 J right-hand sums are
+  // dealt out over the lanes (entry p to lane p % 64: T = 13 / 29 accumulators per lane, in registers); the candidates of the 27 cells
+  // are weighed 64 at a time (lane = candidate), and for every sample that stays the wave lays its row {dinv m_0 .. dinv m_J-1,
+  // dinv ln N_0..3} into LDS -- lane a computes monomial a -- from where each lane reads the two factors of each of its entries.
+  // The products are the reference's (E = dinv * monomial, A = sum E_a E_b); the sums run in cell order.  dposv 'U' and the two
+  // substitutions then run in LDS with lane c on column c, every sum over l in the reference's order.
+  // LDS: area[0, NT + 4 J) the matrix and the right-hand sums (<= 1 820 doubles), area[1888, 1888 + J) y, area[1984, 2048) the row.
+  static constexpr int GEN_MAXORDER = 5, GEN_Y = 1888, GEN_ROW = 1984;
+  __device__ __forceinline__ static double wave_sum(double v) { return across_groups(group_sum(v)); }
+  template <int N>
+  __device__ __forceinline__ static double pick(const double (&tab)[N], int e) {
+    double v = tab[0];
+#pragma unroll
+    for (int k = 1; k < N; ++k) v = (e == k) ? tab[k] : v;
+    return v;
+  }
+  // fi[0..3] = ln N_s at the wave-uniform point pt; all 64 lanes call together.  A failed fit gives zeros (the reference's fi = 0).
+  // (Point and result go through the caller's private arrays on purpose: a call that touches none of its caller's stack is marked
+  // `tail`, which switches the no-callee-saved-registers convention off for the callee -- 24-32 registers saved to AGPRs then, and the
+  // two-waves-per-SIMD kernels that call this function fall to one wave.)
+  template <int T>
+  __device__ __noinline__ void gen_point(const double *pt, SRT_LDS double *area, double *fi) const {
+    const ScatteredModel M = uniform_copy();
+    const double p0 = uni(pt[0]), p1 = uni(pt[1]), p2 = uni(pt[2]);
+    const int lane = threadIdx.x;
+    const int order = M.order, J = (order + 1) * (order + 2) * (order + 3) / 6, NT = J * (J + 1) / 2, NE = NT + 4 * J;
+    const double r2 = M.radius * M.radius;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) fi[s] = 0.0;
+    Rows R;
+    {
+      const double pp[3] = {p0, p1, p2};
+      int cc[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        double t = floor((pp[k] - M.origin[k]) * M.inv_cell);
+        t = fmin(fmax(t, -2.0), (double)M.dims[k] + 1.0);
+        cc[k] = uni((int)t);
+      }
+      R.cy = cc[1];
+      R.cz = cc[2];
+      R.x0 = cc[0] - 1 < 0 ? 0 : cc[0] - 1;
+      R.x1 = cc[0] + 1 >= M.dims[0] ? M.dims[0] - 1 : cc[0] + 1;
+      R.live = true;
+    }
+    // ---- pass 1 (:296-303): how many samples, and the window-weighted mean of their spacings
+    int count = 0;
+    double sw = 0.0, swv = 0.0;
+#pragma unroll 1
+    for (int r = 0; r < 9; ++r) {
+      int lo, hi;
+      M.row_range(R, r, lo, hi);
+#pragma unroll 1
+      for (int i = lo + lane; i < hi; i += 64) {
+        const SRT_AS1 double *q = M.gpts() + (size_t)i * 8;
+        const double d0 = q[0] - p0, d1 = q[1] - p1, d2 = q[2] - p2;
+        const double ss = d0 * d0 + d1 * d1 + d2 * d2;
+        if (ss < r2) {
+          const double cw = 0.5 + 0.5 * cos(sqrt(ss) * 2.0 * PI / M.radius / 2.0);
+          sw += cw;
+          swv += cw * q[7];
+          ++count;
+        }
+      }
+    }
+    count = wave_total(count);
+    if (count < J) return; // status 2
+    sw = wave_sum(sw);
+    swv = wave_sum(swv);
+    const double hin = M.lws * (swv / sw);
+    // ---- pass 2 (:316-323): how many stay above the weight mask; fewer than J: all of them are used
+    int kept = 0;
+#pragma unroll 1
+    for (int r = 0; r < 9; ++r) {
+      int lo, hi;
+      M.row_range(R, r, lo, hi);
+#pragma unroll 1
+      for (int i = lo + lane; i < hi; i += 64) {
+        const SRT_AS1 double *q = M.gpts() + (size_t)i * 8;
+        const double d0 = q[0] - p0, d1 = q[1] - p1, d2 = q[2] - p2;
+        const double ss = d0 * d0 + d1 * d1 + d2 * d2;
+        if (ss < r2 && M.etainv(sqrt(ss), hin) > 1.0e-16) ++kept;
+      }
+    }
+    kept = wave_total(kept);
+    const bool usemask = kept >= J;
+    // ---- this lane's entries (p = lane + 64 t) as the LDS slots of their two factors, and this lane's monomial
+    int ij[T];
+    {
+      int row = 0, rem = lane; // entry p of the packed upper triangle = (row, row + rem)
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const int p = lane + 64 * t;
+        while (row < J && rem >= J - row) {
+          rem -= J - row;
+          ++row;
+        }
+        int ia = row, ib = row + rem;
+        if (p >= NT) {
+          const int q = p - NT;
+          ia = q >> 2;
+          ib = J + (q & 3);
+        }
+        if (p >= NE) ia = ib = 0;
+        ij[t] = ia | (ib << 8);
+        rem += 64;
+      }
+    }
+    int ex = 0, ey = 0, ez = 0;
+    {
+      int n = 0;
+#pragma unroll 1
+      for (int a = 0; a <= order; ++a)
+#pragma unroll 1
+        for (int b = 0; a + b <= order; ++b)
+#pragma unroll 1
+          for (int c = 0; a + b + c <= order; ++c) {
+            if (n == lane) ex = a, ey = b, ez = c;
+            ++n;
+          }
+    }
+    double acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[t] = 0.0;
+    SRT_LDS double *row = area + GEN_ROW;
+    wave_lds_sync();
+    // ---- pass 3: the sums
+#pragma unroll 1
+    for (int r = 0; r < 9; ++r) {
+      int lo, hi;
+      M.row_range(R, r, lo, hi);
+#pragma unroll 1
+      for (int base = lo; base < hi; base += 64) {
+        const int i = base + lane;
+        bool use = false;
+        double d0 = 0.0, d1 = 0.0, d2 = 0.0, dinv = 0.0, f0 = 0.0, f1 = 0.0, f2 = 0.0, f3 = 0.0;
+        if (i < hi) {
+          const SRT_AS1 double *q = M.gpts() + (size_t)i * 8;
+          d0 = q[0] - p0, d1 = q[1] - p1, d2 = q[2] - p2;
+          const double ss = d0 * d0 + d1 * d1 + d2 * d2;
+          if (ss < r2) {
+            const double e = M.etainv(sqrt(ss), hin);
+            use = !usemask || e > 1.0e-16;
+            dinv = sqrt(0.5 * e); // :331-341 (scaled = 0)
+            f0 = q[3], f1 = q[4], f2 = q[5], f3 = q[6];
+          }
+        }
+        unsigned long long todo = __ballot(use);
+#pragma unroll 1
+        while (todo != 0ull) {
+          const int l = __builtin_ctzll(todo);
+          todo &= todo - 1ull;
+          const double D0 = from_lane(d0, l), D1 = from_lane(d1, l), D2 = from_lane(d2, l), W = from_lane(dinv, l);
+          double X[GEN_MAXORDER + 1], Y[GEN_MAXORDER + 1], Z[GEN_MAXORDER + 1];
+          X[0] = Y[0] = Z[0] = 1.0;
+#pragma unroll
+          for (int k = 1; k <= GEN_MAXORDER; ++k) X[k] = X[k - 1] * D0, Y[k] = Y[k - 1] * D1, Z[k] = Z[k - 1] * D2;
+          double val = W * ((pick(X, ex) * pick(Y, ey)) * pick(Z, ez)); // E(i, a) = dinv * monomial (:343-353)
+          const int s = lane - J;
+          const double fs = s == 0 ? from_lane(f0, l) : (s == 1 ? from_lane(f1, l) : (s == 2 ? from_lane(f2, l) : from_lane(f3, l)));
+          val = s >= 0 ? W * fs : val;
+          if (lane < J + 4) row[lane] = val;
+          wave_lds_sync();
+#pragma unroll
+          for (int t = 0; t < T; ++t) {
+            acc[t] = fma(row[ij[t] & 0xFF], row[ij[t] >> 8], acc[t]);
+            // (eight entries' reads in flight at a time: left alone, the scheduler hoists all 2 T of them, and this function -- which the
+            // two-waves-per-SIMD trace kernels call -- must stay inside 256 registers)
+            if ((t & 7) == 7) asm volatile("" ::: "memory");
+          }
+          wave_lds_sync();
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const int p = lane + 64 * t;
+      if (p < NE) area[p] = acc[t];
+    }
+    wave_lds_sync();
+    // ---- dposv 'U' (dpotf2 + dpotrs) on the packed upper triangle; lane c owns column c
+    auto at = [&](int rr, int c) -> SRT_LDS double & { return area[rr * J - rr * (rr - 1) / 2 + (c - rr)]; };
+    const int c = lane;
+#pragma unroll 1
+    for (int j = 0; j < J; ++j) {
+      double t = 0.0;
+      if (c >= j && c < J) {
+#pragma unroll 1
+        for (int l = 0; l < j; ++l) t = t + at(l, c) * at(l, j);
+        t = at(j, c) - t;
+      }
+      const double ajj = from_lane(t, j);
+      if (!(ajj > 0.0)) return; // status 1
+      const double u = sqrt(ajj), inv = 1.0 / u;
+      if (c == j) at(j, c) = u;
+      else if (c > j && c < J) at(j, c) = t * inv;
+      wave_lds_sync();
+    }
+    SRT_LDS double *y = area + GEN_Y;
+#pragma unroll 1
+    for (int i = 0; i < J; ++i) { // U^T z = e_1 (every lane the same sums: the reads are broadcasts)
+      double t = (i == 0) ? 1.0 : 0.0;
+#pragma unroll 1
+      for (int l = 0; l < i; ++l) t = t - at(l, i) * y[l];
+      t = t / at(i, i);
+      if (lane == 0) y[i] = t;
+      wave_lds_sync();
+    }
+#pragma unroll 1
+    for (int i = J - 1; i >= 0; --i) { // U y = z
+      double t = y[i];
+#pragma unroll 1
+      for (int l = i + 1; l < J; ++l) t = t - at(i, l) * y[l];
+      t = t / at(i, i);
+      if (lane == 0) y[i] = t;
+      wave_lds_sync();
+    }
+    double fs = 0.0; // lane s < 4: species s
+#pragma unroll 1
+    for (int j = 0; j < J; ++j) fs = fs + y[j] * area[NT + 4 * j + (lane & 3)];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) fi[s] = from_lane(fs, s);
+    wave_lds_sync();
+  }
+  __device__ __forceinline__ Fit4 gen_fit(double p0, double p1, double p2, SRT_LDS double *area) const {
+    double pt[3] = {p0, p1, p2}, fi[4];
+    if (order == 4) gen_point<13>(pt, area, fi);
+    else gen_point<29>(pt, area, fi);
+    Fit4 out;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) out.v[s] = fi[s];
+    return out;
+  }
+  // densities of the stencils of the lanes with need == true, one point after the other (out as coop_stencil's)
+  __device__ __noinline__ void gen_stencil(const double *c, const double *d, const double *extra, int npts, bool need, double *out,
+                                           SRT_LDS double *area) const {
+    const int lane = threadIdx.x;
+    const int ns = uni(nspec);
+    const unsigned long long needmask = __ballot(need);
+#pragma unroll 1
+    for (int j = 0; j < 64; ++j) {
+      if (!((needmask >> j) & 1ull)) continue; // wave-uniform
+      double oc[3], od[3], oe[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        oc[k] = from_lane(c[k], j);
+        od[k] = from_lane(d[k], j);
+        oe[k] = (npts > 7) ? from_lane(extra[k], j) : 0.0;
+      }
+#pragma unroll 1
+      for (int g = 0; g < npts; ++g) {
+        double p[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          double v = oc[k];
+          v = (g == 1 + 2 * k) ? oc[k] + od[k] : v;
+          v = (g == 2 + 2 * k) ? oc[k] - od[k] : v;
+          v = (g == 7) ? oe[k] : v;
+          p[k] = v;
+        }
+        const bool outside = p[0] * p[0] + p[1] * p[1] + p[2] * p[2] > R_E * R_E; // (:307-309)
+        Fit4 fi;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) fi.v[s] = 0.0;
+        if (outside) fi = gen_fit(p[0], p[1], p[2], area);
+        if (lane == j) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) out[4 * g + s] = (outside && s < ns) ? exp(fi.v[s]) : 0.0;
+        }
+      }
+    }
+  }
+
   // out[8][4] (per lane): densities at the lane's stencil points 0..npts-1 (point 7 = extra).  All 64 lanes call
   // together; lanes with need == false are not served (their out is left untouched).
   //
@@ -2430,7 +2706,8 @@ struct ScatteredModel {
     double cc[3] = {c[0], c[1], c[2]}, dd[3] = {d[0], d[1], d[2]};
     double ee[3] = {NE ? extra[0] : 0.0, NE ? extra[1] : 0.0, NE ? extra[2] : 0.0};
     SRT_LDS int *lists = (SRT_LDS int *)lds;
-    if (order == 0) coop_stencil<1>(cc, dd, ee, 7 + NE, need, out, lists);
+    if (order > 3) gen_stencil(cc, dd, ee, 7 + NE, need, out, (SRT_LDS double *)lds);
+    else if (order == 0) coop_stencil<1>(cc, dd, ee, 7 + NE, need, out, lists);
     else if (order == 1) coop_stencil<4>(cc, dd, ee, 7 + NE, need, out, lists);
     else if (order == 2) coop_stencil<10>(cc, dd, ee, 7 + NE, need, out, lists);
     else coop_stencil<20>(cc, dd, ee, 7 + NE, need, out, lists);
@@ -2441,7 +2718,37 @@ struct ScatteredModel {
   }
 
   template <int NP>
-  __device__ __forceinline__ void density(const double (&p)[NP][3], double (&Ns)[NP][4], double *) const {
+  __device__ __forceinline__ void density(const double (&p)[NP][3], double (&Ns)[NP][4], double *lds) const {
+    if (order > 3) { // wave-uniform; all 64 lanes are here (the layered kernels clamp their item index)
+      const int lane = threadIdx.x;
+      const int ns = uni(nspec);
+#pragma unroll 1
+      for (int i = 0; i < NP; ++i)
+#pragma unroll 1
+        for (int j = 0; j < 64; ++j) {
+          double x[3];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            double v = p[0][k];
+#pragma unroll
+            for (int q = 1; q < NP; ++q) v = (i == q) ? p[q][k] : v;
+            x[k] = from_lane(v, j);
+          }
+          const bool outside = x[0] * x[0] + x[1] * x[1] + x[2] * x[2] > R_E * R_E;
+          Fit4 fi;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) fi.v[s] = 0.0;
+          if (outside) fi = gen_fit(x[0], x[1], x[2], (SRT_LDS double *)lds);
+          if (lane == j) {
+#pragma unroll
+            for (int q = 0; q < NP; ++q)
+#pragma unroll
+              for (int s = 0; s < 4; ++s)
+                if (q == i) Ns[q][s] = (outside && s < ns) ? exp(fi.v[s]) : 0.0;
+          }
+        }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < NP; ++i) { // static indices; the interpolator itself is one out-of-line copy per order
       double x[3] = {p[i][0], p[i][1], p[i][2]}, n4[4];

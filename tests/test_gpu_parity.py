@@ -199,6 +199,70 @@ def test_g2_scattered_order3_gradients(scat_o3, pointsfile):
     assert np.median(ex) <= 1e-5 and np.percentile(ex, 90) <= 1e-3
 
 
+@pytest.fixture(scope="module")
+def scat_o45():
+    import os
+
+    from conftest import GOLDEN_DIR
+    return np.load(os.path.join(GOLDEN_DIR, "scattered_o45_golden.npz"))
+
+
+@pytest.mark.parametrize("order", [4, 5])
+def test_scattered_orders_4_and_5(scat_o45, pointsfile, order):
+    """The generate_monomials orders (lsinterp_mod.f95:114-164, 273-281; J = 35 / 56) through srt_scattered.hpp's gen_point: the
+    layered kernels (funcPlasmaParams: one point per lane, the wave fitting them one after the other) and the stencil service of the
+    gradient / trace kernels (gen_stencil), against the reference's own outputs and against the oracle where the reference's
+    tree-root quirk reaches (as test_g0_scattered_params).  With the narrow window the fits that have fewer samples than monomials
+    answer exp(0) = 1 like the reference's."""
+    from oracle import oracle
+    from stanford_raytracer_amd import api
+
+    ws = float(scat_o45["window_scale"])
+    x, rootp = scat_o45["g0_x"], scat_o45["ref_root_point"]
+    for key, w in (("g0_o%d_out" % order, ws), ("g0_o%d_narrow_out" % order, 1.5)):
+        ref = scat_o45[key]
+        xs = x[:len(ref)]
+        m = api.Model.scattered_file(pointsfile, order=order, window_scale=w)
+        g = m.plasma_params(xs)
+        assert np.array_equal(g[:, 0:4], ref[:, 0:4]) and np.array_equal(g[:, 8:12], ref[:, 8:12])
+        near = np.linalg.norm(xs - rootp, axis=1) < float(scat_o45["ref_maxnearest"]) * w
+        o = oracle.Model.scattered_file(pointsfile, perm_seed=2 | 0x80000000, order=order, window_scale=w)  # true distances
+        want = ref[:, 4:8].copy()
+        if near.any():
+            want[near] = np.array([np.concatenate(o.plasma_params(p)) for p in xs[near]])[:, 4:8]
+        assert np.array_equal(g[:, 4] == 1.0, want[:, 0] == 1.0)      # the same fits fail
+        e = np.abs(g[:, 4:8] - want) / want
+        assert e.max() <= (1e-9 if w == ws else 1e-6), e.max()
+    m = api.Model.scattered_file(pointsfile, order=order, window_scale=ws)
+    gin, ref = scat_o45["g2_in"], scat_o45["g2_o%d_out" % order]
+    far = np.linalg.norm(gin[:, 0:3] - rootp, axis=1) >= float(scat_o45["ref_maxnearest"]) * ws
+    assert far.sum() >= 16
+    g = m.gradients(gin[:, 0:3], gin[:, 3:6], gin[:, 6], 1e-6)
+    assert vrel(g[far, 0:3], ref[far, 0:3]).max() <= 1e-7
+    assert (np.abs(g[far, 3] - ref[far, 3]) / np.abs(ref[far, 3])).max() <= 1e-6
+    ex = vrel(g[far, 4:7], ref[far, 4:7])   # d(ln N) over a 10 m stencil: 1e-12 / 1e-6 amplification
+    assert np.median(ex) <= 1e-4 and np.percentile(ex, 90) <= 1e-2, (np.median(ex), np.percentile(ex, 90))
+    if order == 4:
+        prm, rays = scat_o45["g4_o4_params"], scat_o45["rays"]
+        rows, nrows, stop, _ = m.trace(rays[:, :3], rays[:, 3:6], rays[:, 6], outputper=1, dt0=prm[0], dtmax=prm[1], tmax=prm[2],
+                                       maxerr=prm[3], minalt=prm[4], maxsteps=int(prm[5]), root=int(prm[6]), fixedstep=1, del_=1e-6)
+        clear = np.array([np.linalg.norm(scat_o45["g4_o4_rows"][i, :6, 1:4] - rootp, axis=1).min() for i in range(len(rays))]) \
+            >= float(scat_o45["ref_maxnearest"]) * ws
+        assert clear.sum() >= 4
+        assert np.array_equal(nrows, scat_o45["g4_o4_nrows"]) and np.array_equal(stop, scat_o45["g4_o4_stop"])
+        ref_rows = scat_o45["g4_o4_rows"]
+        assert np.array_equal(rows[:, :6, 0], ref_rows[:, :6, 0])
+        assert np.allclose(rows[clear, :6, 1:4], ref_rows[clear, :6, 1:4], rtol=1e-5, atol=0)
+        assert np.allclose(rows[clear, :6, 16:20], ref_rows[clear, :6, 16:20], rtol=1e-5, atol=0)
+
+
+def test_scattered_order_6_is_refused(pointsfile):
+    from stanford_raytracer_amd import api
+
+    with pytest.raises(Exception, match="orders 0..5"):
+        api.Model.scattered_file(pointsfile, order=6)
+
+
 def test_scattered_vs_oracle_ladder(gpu_models, oracle_scattered):
     from stanford_raytracer_amd import workloads as wl
 
