@@ -887,6 +887,8 @@ extern "C" int srt_model_create_scattered_file_root(const char *ptsfile, int yea
   s.radius = h.radius;
   s.lws = local_window_scale;
   s.bmargin = bmargin;
+  s.u11 = 1.1 * std::pow(h.radius * (1.0 + 5.0e-16), 1.1);
+  s.inv_radius = 1.0 / h.radius;
   s.nspec = h.nspec;
   s.order = order;
   s.exact = exact;

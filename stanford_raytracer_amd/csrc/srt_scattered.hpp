@@ -188,6 +188,7 @@ struct ScatteredModel {
   const double *xyz;     // [3][npts]: the positions once more, SoA (candidate scans: 24 coalesced bytes per sample, not 64)
   const int *cell_start; // [ncells + 1]
   double origin[3], inv_cell, radius, lws;
+  double u11, inv_radius; // 1.1 (radius (1 + 5e-16))**1.1 and 1 / radius: per-model constants of the second-order tier's test (sf_weights)
   double bmargin; // candidate blocks (coop_stencil) hold the samples within radius * (1 + bmargin) of their centre; the grid's cell edge is that too
   int dims[3];
   int nspec, order, exact, npts;
@@ -224,6 +225,8 @@ struct ScatteredModel {
     M.radius = uni(self->radius);
     M.lws = uni(self->lws);
     M.bmargin = uni(self->bmargin);
+    M.u11 = uni(self->u11);
+    M.inv_radius = uni(self->inv_radius);
     M.nspec = uni(self->nspec);
     M.order = uni(self->order);
     M.exact = uni(self->exact);
@@ -562,6 +565,10 @@ struct ScatteredModel {
 // series of the difference and the addition theorem), and -- for a stencil all of whose samples are far enough -- the seven weights
 // from a second-order expansion of the weight about the centre (sf_weights); 0: round 3's series everywhere.
 #define SRT_SCAT_TAYLOR 1
+#endif
+#ifndef SRT_SCAT_REC_AHEAD
+// 1: the weights pass reads the staging records of the samples beyond the LDS side arrays one trip ahead (second-order tier)
+#define SRT_SCAT_REC_AHEAD 1
 #endif
 #ifndef SRT_SCAT_FUSED
 // 1: the weights and the pair loop of the shared path run FUSED, tile by tile (sf_fused): the 64 records of a tile --
@@ -919,7 +926,8 @@ struct ScatteredModel {
     const double o7[3] = {pg[7][0] - pg[0][0], pg[7][1] - pg[0][1], pg[7][2] - pg[0][2]};
     const double o7sq = o7[0] * o7[0] + o7[1] * o7[1] + o7[2] * o7[2];
     double rmin_l = 1.0e300; // (this lane's samples)
-    // (one sample ahead: the next gather is in flight while this sample is worked on)
+    // (one sample ahead: the next gather is in flight while this sample is worked on; issuing the first one before the points are
+    // handed round above was measured: no gain)
     d2_t na = {0.0, 0.0}, nb = na, nc = na, nd = na;
     if (lane < n_list) {
       const SRT_AS1 d2_t *q = (const SRT_AS1 d2_t *)(M.gpts() + (size_t)list[lane] * 8);
@@ -1152,8 +1160,8 @@ struct ScatteredModel {
     if constexpr (SRT_SCAT_TAYLOR != 0) {
       const double rmin = uni(o->rmin);
       if (base_ok && rmin > 0.0) {
-        const double irm = fdiv(1.0, rmin + reps), iR = fdiv(1.0, radius);
-        const double umax = 1.1 * (radius + reps) * fm::exp_any(0.1 * fm::log_pos(radius + reps)) * sh; // 1.1 u at the radius
+        const double irm = fdiv(1.0, rmin + reps), iR = M.inv_radius;
+        const double umax = M.u11 * sh; // 1.1 u at the radius (u11: the model's constant 1.1 (radius + reps)**1.1 -- a log + exp chain per stencil before)
         tay_all = dmax6 * irm <= 1.0e-3 && umax * (dmax6 * iR) <= 2.0e-4 && umax * etamax6 <= 2.0e-4 &&
                   (!fit8[7] || (p7near && d7 * irm <= 1.0e-3 && umax * (d7 * iR) <= 2.0e-4 && umax * eta7 <= 2.0e-4));
 #ifdef SRT_PHASE_TIMING
@@ -1353,11 +1361,29 @@ struct ScatteredModel {
     if (tay_all) { // (wave-uniform)
 #pragma unroll 1
       for (int k = lane; k < nlds; k += 64) weigh_taylor(k, side.a[k], side.b[k], side.c[k]);
+#if SRT_SCAT_REC_AHEAD
+      // (a list longer than the side arrays -- most are: 423 samples on average against 306 slots: the rest comes back from the staging
+      // records, one trip AHEAD, so that a trip's loads are not what its first instruction waits for)
+      {
+        int k = nlds + lane;
+        const d2_t z2 = d2_t{0.0, 0.0};
+        d2_t n0 = z2, n1 = z2, n4 = z2, n5 = z2;
+        if (k < n_list) n0 = *chunk(rec, 0, k), n1 = *chunk(rec, 1, k), n4 = *chunk(rec, 4, k), n5 = *chunk(rec, 5, k);
+#pragma unroll 1
+        for (; k < n_list; k += 64) {
+          const d2_t c0 = n0, c1 = n1, c4 = n4, c5 = n5;
+          const int kn = k + 64;
+          if (kn < n_list) n0 = *chunk(rec, 0, kn), n1 = *chunk(rec, 1, kn), n4 = *chunk(rec, 4, kn), n5 = *chunk(rec, 5, kn);
+          weigh_taylor(k, c0, d2_t{c1.x, c4.x}, c5);
+        }
+      }
+#else
 #pragma unroll 1
       for (int k = nlds + lane; k < n_list; k += 64) {
         const d2_t c0 = *chunk(rec, 0, k), c1 = *chunk(rec, 1, k), c4 = *chunk(rec, 4, k), c5 = *chunk(rec, 5, k);
         weigh_taylor(k, c0, d2_t{c1.x, c4.x}, c5);
       }
+#endif
     } else {
 #pragma unroll 1
     for (int k = lane; k < nlds; k += 64) weigh(k, side.a[k], side.b[k], side.c[k]);
@@ -1400,6 +1426,25 @@ struct ScatteredModel {
     double Mm[J == 10 ? Moments::N : 1]; // order 2: the 35 moments stand in for the 55 entries of A while summing
     typename std::conditional<O3, Sums20, int>::type S20;
     kept_out = pass1_out(list)->kept8[g]; // (counted where the weights were made; the park area is outside the ring)
+    // The records come back through a ring of NBUF 64-record buffers in LDS (the list area: the list is dead by now),
+    // filled by LDS-DMA NBUF - 1 buffers ahead -- the staging buffers of the CU's waves do not stay in L2 (the scans of
+    // the other waves stream through it).
+    // Buffer layout: [16-byte chunk t of the record][record] -- DMA instruction t moves chunk t of 64 records (lane =
+    // record), and the 8 lanes of a group read 8 neighbouring 16-byte slots (all 8 groups the same ones: broadcast).
+    const int nchunk = (n_list + 63) >> 6; // wave-uniform
+    SRT_AS3 char *const ring = (SRT_AS3 char *)list;
+    auto issue = [&](int c) {
+      const int r = c * 64 + lane;
+      const int rc = r < n_list ? r : n_list - 1; // (x, y, z, ln N of the last sample behind the end: finite; the weights there are zero)
+      SRT_AS3 char *dst = ring + (c % NBUF) * 8192;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) // (chunk-major staging: instruction t reads 1 KiB of consecutive bytes)
+        __builtin_amdgcn_global_load_lds((const SRT_AS1 void *)chunk(rec, t, t < 4 ? rc : r), (SRT_AS3 void *)(dst + 1024 * t), 16, 0, 0);
+    };
+    const bool any = __any(fit);
+    if (any) { // (first thing: the first buffers are on their way while the sums are zeroed)
+      for (int c = 0; c < NBUF - 1 && c < nchunk; ++c) issue(c);
+    }
     if constexpr (O3) S20.zero();
 #pragma unroll
     for (int t = 0; t < ((O3 || J == 10) ? 1 : NT); ++t) A[t] = 0.0;
@@ -1443,26 +1488,7 @@ struct ScatteredModel {
         }
       }
     };
-    // The records come back through a ring of NBUF 64-record buffers in LDS (the list area: the list is dead by now),
-    // filled by LDS-DMA NBUF - 1 buffers ahead -- the staging buffers of the CU's waves do not stay in L2 (the scans of
-    // the other waves stream through it).
-    // Buffer layout: [16-byte chunk t of the record][record] -- DMA instruction t moves chunk t of 64 records (lane =
-    // record), and the 8 lanes of a group read 8 neighbouring 16-byte slots (all 8 groups the same ones: broadcast).
     {
-      const int nchunk = (n_list + 63) >> 6; // wave-uniform
-      SRT_AS3 char *const ring = (SRT_AS3 char *)list;
-      auto issue = [&](int c) {
-        const int r = c * 64 + lane;
-        const int rc = r < n_list ? r : n_list - 1; // (x, y, z, ln N of the last sample behind the end: finite; the weights there are zero)
-        SRT_AS3 char *dst = ring + (c % NBUF) * 8192;
-#pragma unroll
-        for (int t = 0; t < 8; ++t) // (chunk-major staging: instruction t reads 1 KiB of consecutive bytes)
-          __builtin_amdgcn_global_load_lds((const SRT_AS1 void *)chunk(rec, t, t < 4 ? rc : r), (SRT_AS3 void *)(dst + 1024 * t), 16, 0, 0);
-      };
-      const bool any = __any(fit);
-      if (any) {
-        for (int c = 0; c < NBUF - 1 && c < nchunk; ++c) issue(c);
-      }
       const int slot = (g == 7) ? 15 : 8 + g;
       const unsigned ring0 = (unsigned)(unsigned long long)ring + (unsigned)(sub * 16);
       const unsigned slot_off = (unsigned)((slot >> 1) * 1024 + (slot & 1) * 8);
@@ -2537,12 +2563,21 @@ struct ScatteredModel {
       // the owner's stencil, and this group's point of it
       double p[3];
       {
+        // this lane's stencil, all nine numbers fetched TOGETHER: c, d, extra point into the caller's private memory (flat loads),
+        // and read where they are used -- each behind the previous one's v_readlane -- they were six round trips in a row per
+        // stencil.  (Kept in registers across the owner loop instead they are spilled and come back one by one: measured in the
+        // listing, 161 scratch operations against 140.)
+        double mc[3], md[3], me[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) mc[k] = c[k], md[k] = d[k], me[k] = extra[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) asm volatile("" : "+v"(mc[k]), "+v"(md[k]), "+v"(me[k]));
         double oc[3], od[3], oe[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-          oc[k] = from_lane(c[k], j); // (j is wave-uniform: v_readlane, no LDS round trip)
-          od[k] = from_lane(d[k], j);
-          oe[k] = (npts > 7) ? from_lane(extra[k], j) : 0.0;
+          oc[k] = from_lane(mc[k], j); // (j is wave-uniform: v_readlane, no LDS round trip)
+          od[k] = from_lane(md[k], j);
+          oe[k] = (npts > 7) ? from_lane(me[k], j) : 0.0;
         }
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
