@@ -256,6 +256,40 @@ def test_scattered_orders_4_and_5(scat_o45, pointsfile, order):
         assert np.allclose(rows[clear, :6, 16:20], ref_rows[clear, :6, 16:20], rtol=1e-5, atol=0)
 
 
+def test_scattered_orders_4_and_5_other_shapes(tmp_path, pointsfile):
+    """The same path where the reference-held fixture does not go: the exact window (exact = 1: exp(r^2 / h^2) weights) at order 4,
+    and a two-species sample file at order 5 (the unused right-hand sums must stay out of the answer) -- against the oracle with
+    true distances, which the CPU suite holds to the reference at these orders."""
+    import os
+
+    from conftest import GOLDEN_DIR
+    from oracle import oracle
+    from stanford_raytracer_amd import api, workloads as wl
+
+    pos, _, _ = wl.launch_set(160, 4242)
+    pos = pos * 0.9
+    m = api.Model.scattered_file(pointsfile, order=4, exact=1, local_window_scale=2.0, window_scale=2.5)
+    o = oracle.Model.scattered_file(pointsfile, perm_seed=2 | 0x80000000, order=4, exact=1, local_window_scale=2.0, window_scale=2.5)
+    g = m.plasma_params(pos)
+    want = np.array([np.concatenate(o.plasma_params(p)) for p in pos])
+    fitted = (want[:, 4] > 0) & (want[:, 4] != 1.0)
+    assert fitted.sum() >= 100
+    assert np.array_equal(g[:, 4] == 1.0, want[:, 4] == 1.0) and np.array_equal(g[:, 4] == 0.0, want[:, 4] == 0.0)
+    e = np.abs(g[fitted, 4:8] - want[fitted, 4:8]) / want[fitted, 4:8]
+    assert e.max() <= 1e-7 and np.median(e) <= 1e-11, (e.max(), np.median(e))   # the exact window's weights span 1e16: looser at the top
+    g0 = np.load(os.path.join(GOLDEN_DIR, "points5500.npz"))
+    two = str(tmp_path / "two_species.txt")
+    wl.write_points_file(two, g0["pts"], g0["lnN"][:, :2], g0["bounds"], g0["qs"][:2], g0["ms"][:2])
+    m2 = api.Model.scattered_file(two, order=5, window_scale=2.5)
+    o2 = oracle.Model.scattered_file(two, perm_seed=2 | 0x80000000, order=5, window_scale=2.5)
+    g2 = m2.plasma_params(pos[:64])
+    w2 = np.array([np.concatenate(o2.plasma_params(p)) for p in pos[:64]])
+    assert np.array_equal(g2[:, 6:8], np.zeros((64, 2))) and np.array_equal(w2[:, 6:8], np.zeros((64, 2)))
+    ok = (w2[:, 4] > 0) & (w2[:, 4] != 1.0)
+    assert ok.sum() >= 40 and np.array_equal(g2[:, 4] == 1.0, w2[:, 4] == 1.0)
+    assert (np.abs(g2[ok, 4:6] - w2[ok, 4:6]) / w2[ok, 4:6]).max() <= 1e-9
+
+
 def test_scattered_order_6_is_refused(pointsfile):
     from stanford_raytracer_amd import api
 
