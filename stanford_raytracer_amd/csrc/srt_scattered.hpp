@@ -18,6 +18,7 @@
 namespace srt {
 
 #define SRT_LDS __attribute__((address_space(3)))
+#define SRT_PRIV __attribute__((address_space(5)))
 typedef float f4_t __attribute__((ext_vector_type(4)));
 
 // Build with -DSRT_PHASE_TIMING for a cycle breakdown of coop_stencil (srt_phase_cycles[], printed after every trace
@@ -2557,6 +2558,11 @@ struct ScatteredModel {
     const unsigned long long needmask = __ballot(need);
     double *const rec = (double *)((SRT_LDS unsigned long long *)lists)[LDS_SCRATCH_SLOT]; // nullptr: no staging buffer
     SRT_AS1 f4_t *const blocks = (SRT_AS1 f4_t *)((SRT_LDS unsigned long long *)lists)[LDS_BLOCK_SLOT]; // nullptr: none
+    // c, d, extra and out are arrays in the CALLER's private memory (density_stencil): addressed as such -- scratch loads / stores --
+    // not through the generic pointers they arrive as.  A flat access counts in lgkmcnt too, so the LDS-only syncs of the hand-off
+    // (s_waitcnt lgkmcnt(0)) waited for the owner's 32 result stores to complete after all.
+    const SRT_PRIV double *const cpv = (const SRT_PRIV double *)c, *const dpv = (const SRT_PRIV double *)d, *const epv = (const SRT_PRIV double *)extra;
+    SRT_PRIV double *const outp = (SRT_PRIV double *)out;
 #pragma unroll 1
     for (int j = 0; j < 64; ++j) {
       if (!((needmask >> j) & 1ull)) continue; // wave-uniform
@@ -2569,7 +2575,7 @@ struct ScatteredModel {
         // listing, 161 scratch operations against 140.)
         double mc[3], md[3], me[3];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) mc[k] = c[k], md[k] = d[k], me[k] = extra[k];
+        for (int k = 0; k < 3; ++k) mc[k] = cpv[k], md[k] = dpv[k], me[k] = epv[k];
 #pragma unroll
         for (int k = 0; k < 3; ++k) asm volatile("" : "+v"(mc[k]), "+v"(md[k]), "+v"(me[k]));
         double oc[3], od[3], oe[3];
@@ -2609,7 +2615,7 @@ struct ScatteredModel {
       const unsigned long long livemask = __ballot(live);
       if (livemask == 0ull) { // the whole stencil is inside the Earth
         if (lane == j)
-          for (int t = 0; t < 4 * npts; ++t) out[t] = 0.0;
+          for (int t = 0; t < 4 * npts; ++t) outp[t] = 0.0;
         continue;
       }
       SRT_PHASE_BEGIN(lists);
@@ -2700,10 +2706,10 @@ struct ScatteredModel {
           for (int gg = 0; gg < 8; ++gg) {
             const d2_t a = park[2 * gg], b = park[2 * gg + 1];
             if (gg < npts) {
-              out[gg * 4 + 0] = a.x;
-              out[gg * 4 + 1] = a.y;
-              out[gg * 4 + 2] = b.x;
-              out[gg * 4 + 3] = b.y;
+              outp[gg * 4 + 0] = a.x;
+              outp[gg * 4 + 1] = a.y;
+              outp[gg * 4 + 2] = b.x;
+              outp[gg * 4 + 3] = b.y;
             }
           }
         }
