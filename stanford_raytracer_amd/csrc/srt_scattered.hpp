@@ -2541,6 +2541,7 @@ struct ScatteredModel {
     }
   }
 
+  __device__ __noinline__ static double exp_handoff(double y) { return fm::exp_any(y); }
   // out[8][4] (per lane): densities at the lane's stencil points 0..npts-1 (point 7 = extra).  All 64 lanes call
   // together; lanes with need == false are not served (their out is left untouched).
   //
@@ -2698,7 +2699,9 @@ struct ScatteredModel {
         // (lane (g, sub < 4) hands over species sub: one exponential per lane; sf_sums<10> fills only that one)
         const int sm = lane & 3;
         const double fm_ = sm == 0 ? fi.v[0] : (sm == 1 ? fi.v[1] : (sm == 2 ? fi.v[2] : fi.v[3]));
-        const double val = (live && sm < nspec) ? fm::exp_any(fm_) : 0.0; // failed fit: fi = 0 -> Ns = 1
+        // (out of line on purpose: inlined here, the exponential's eleven constants were hoisted out of the owner loop, spilled, and came
+        // back from scratch one at a time inside its dependent chain -- eight round trips per stencil, most of the hand-off's 7 k cycles)
+        const double val = (live && sm < nspec) ? exp_handoff(fm_) : 0.0; // failed fit: fi = 0 -> Ns = 1
         if ((lane & 7) < 4) ((SRT_LDS double *)park)[4 * g + sm] = val;
         wave_lds_sync();
         if (lane == j) {
