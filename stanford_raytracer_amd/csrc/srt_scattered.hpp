@@ -898,7 +898,7 @@ struct ScatteredModel {
     const ScatteredModel M = uniform_copy();
     const double p[3] = {p_in[0], p_in[1], p_in[2]};
     const double radius = M.radius, lws = M.lws;
-    SRT_AS1 double *const rec = (SRT_AS1 double *)rec_flat; // device memory: global loads / stores, not flat ones
+    SRT_AS1 double *const rec = (SRT_AS1 double *)uni(rec_flat); // (wave-uniform: in scalar registers -- as an argument it arrives in vector registers, was spilled and came back from scratch every trip) // device memory: global loads / stores, not flat ones
     const int lane = threadIdx.x;
     const double r2 = radius * radius;
     const double pi_R = PI / radius;
@@ -1110,7 +1110,7 @@ struct ScatteredModel {
     const ScatteredModel M = uniform_copy();
     const double p[3] = {p_in[0], p_in[1], p_in[2]};
     const double radius = M.radius;
-    SRT_AS1 double *const rec = (SRT_AS1 double *)rec_flat;
+    SRT_AS1 double *const rec = (SRT_AS1 double *)uni(rec_flat);
     const int lane = threadIdx.x, g = lane >> 3;
     const double r2 = radius * radius, pi_R = PI / radius, reps = radius * 5.0e-16;
     SRT_PHASE_BEGIN(list);
@@ -1418,7 +1418,7 @@ struct ScatteredModel {
                                        int &kept_out) const {
     Fit4 fi;
     const double p[3] = {p_in[0], p_in[1], p_in[2]}; // in registers: the asm statements below clobber memory
-    SRT_AS1 double *const rec = (SRT_AS1 double *)rec_flat;
+    SRT_AS1 double *const rec = (SRT_AS1 double *)uni(rec_flat);
     const int lane = threadIdx.x, g = lane >> 3, sub = lane & 7;
     constexpr int NT = J * (J + 1) / 2;
     SRT_PHASE_BEGIN(list);
